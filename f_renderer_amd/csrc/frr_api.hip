@@ -1,0 +1,644 @@
+// frr_api.hip -- host side of libfrr_hip.so: the C ABI of include/frr.h over the kernels in
+// frr_kernels.h.  gfx950 only; no CPU fallback (every compute entry point needs the device).
+#include "frr_kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+using namespace frr;
+
+namespace {
+
+enum KernelId { KID_CLEAR, KID_GEOM_COUNT, KID_SCAN_BLOCKS, KID_GEOM_EMIT, KID_GEOM_EMIT_CLIP, KID_BIN_COUNT,
+                KID_TILE_SCAN, KID_BIN_FILL, KID_RASTER, KID_COUNT };
+const char *const kKernelNames[KID_COUNT] = {"k_clear", "k_geom_count", "k_scan_blocks", "k_geom_emit",
+                                             "k_geom_emit_clip", "k_bin_count", "k_tile_scan", "k_bin_fill",
+                                             "k_raster"};
+
+struct Mesh {
+    const float *dev = nullptr;
+    bool owned = false, used = false;
+    uint64_t ntris = 0;
+    int vs = 0;
+};
+struct Texture {
+    uint8_t *dev = nullptr;
+    uint32_t w = 0, h = 0;
+};
+struct ProfRec { int kid; hipEvent_t a, b; };
+
+} // namespace
+
+struct frr_ctx {
+    int device = 0;
+    uint32_t W = 0, H = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint8_t *color = nullptr, *own_color = nullptr;
+    float *depth = nullptr, *own_depth = nullptr;
+    uint32_t *tri_id = nullptr, *own_tri_id = nullptr;
+    Counters *cnt = nullptr;
+    // geometry workspace
+    uint32_t *block_sums = nullptr; size_t block_sums_cap = 0;
+    uint2 *clip_list = nullptr; size_t clip_cap = 0;
+    RasterRec *recs = nullptr; size_t setup_cap = 0; size_t setup_hint = 0;
+    float *vary = nullptr; size_t vary_cap = 0; // floats
+    // binning workspace
+    uint32_t *tile_counts = nullptr, *tile_offsets = nullptr, *tile_cursor = nullptr;
+    uint32_t max_tiles = 0;
+    uint32_t *bins = nullptr; size_t bin_cap = 0;
+    std::vector<Mesh> meshes;
+    Texture tex[FRR_MAX_TEXTURES];
+    frr_uniforms uni;
+    DevUniforms duni;
+    int geom_vs = -1;         // VS of the last frr_geometry
+    uint64_t geom_ntris = 0;
+    int rank = 0, world = 1;
+    hipEvent_t ev[16] = {};
+    bool ev_set[16] = {};
+    bool profiling = false;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[KID_COUNT] = {};
+    uint32_t prof_n[KID_COUNT] = {};
+    std::string err;
+};
+
+namespace {
+
+int fail(frr_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+#define HIP_TRY(c, expr)                                                                                    \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(c, FRR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+template <typename T> int ensure(frr_ctx *c, T *&p, size_t &cap, size_t need)
+{
+    if (need <= cap && p) return FRR_OK;
+    if (p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(p)); p = nullptr; cap = 0; }
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, need * sizeof(T));
+    if (e != hipSuccess) return fail(c, FRR_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    p = (T *)q;
+    cap = need;
+    return FRR_OK;
+}
+
+hipEvent_t get_event(frr_ctx *c)
+{
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    frr_ctx *c; int kid; hipEvent_t a = nullptr;
+    ProfScope(frr_ctx *c_, int kid_) : c(c_), kid(kid_)
+    {
+        if (c->profiling) { a = get_event(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~ProfScope()
+    {
+        if (c->profiling) { hipEvent_t b = get_event(c); (void)hipEventRecord(b, c->stream); c->prof_pending.push_back({kid, a, b}); }
+    }
+};
+void prof_collect(frr_ctx *c)
+{
+    if (c->prof_pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &r : c->prof_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof_ms[r.kid] += ms; c->prof_n[r.kid]++; }
+        c->ev_pool.push_back(r.a); c->ev_pool.push_back(r.b);
+    }
+    c->prof_pending.clear();
+}
+
+// glam Mat4*Mat4 = columns (self * rhs.col_j), Mat4*Vec4 = ((c0*x + c1*y) + c2*z) + c3*w
+void h_mat4_mul(const float *a, const float *b, float *out)
+{
+    float t[16];
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r)
+            t[4 * c + r] = ((a[r] * b[4 * c] + a[4 + r] * b[4 * c + 1]) + a[8 + r] * b[4 * c + 2]) + a[12 + r] * b[4 * c + 3];
+    memcpy(out, t, sizeof t);
+}
+
+void refresh_dev_uniforms(frr_ctx *c)
+{
+    DevUniforms &d = c->duni;
+    float pv[16];
+    h_mat4_mul(c->uni.proj, c->uni.view, pv);   // proj * view * model is left-associative (phong.rs:119)
+    h_mat4_mul(pv, c->uni.model, d.mvp);
+    memcpy(d.model, c->uni.model, sizeof d.model);
+    memcpy(d.view_pos, c->uni.view_pos, sizeof d.view_pos);
+    memcpy(d.light_pos, c->uni.light_pos, sizeof d.light_pos);
+    memcpy(d.light_color, c->uni.light_color, sizeof d.light_color);
+    d.ambient_strength = c->uni.ambient_strength;
+    d.specular_strength = c->uni.specular_strength;
+    memcpy(d.flat_color, c->uni.flat_color, sizeof d.flat_color);
+    int s = c->uni.texture_slot;
+    if (s >= 0 && s < FRR_MAX_TEXTURES) { d.tex = c->tex[s].dev; d.tex_w = c->tex[s].w; d.tex_h = c->tex[s].h; }
+    else { d.tex = nullptr; d.tex_w = d.tex_h = 0; }
+}
+
+int check_frame_counters(frr_ctx *c, Counters *host)
+{
+    Counters h;
+    HIP_TRY(c, hipMemcpyAsync(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (host) *host = h;
+    if (h.overflow) {
+        // grow what overflowed so that re-issuing the frame succeeds
+        if (h.overflow & 2u) {
+            size_t need = (size_t)(h.bin_total + h.bin_total / 4 + 1024);
+            if (ensure(c, c->bins, c->bin_cap, need) != FRR_OK) return FRR_ERR_NOMEM;
+        }
+        if (h.overflow & 1u) c->setup_hint = (size_t)h.need_setup + h.need_setup / 8 + 1024;
+        return fail(c, FRR_ERR_CAPACITY, "device work list overflowed; capacity grown, re-issue the frame");
+    }
+    return FRR_OK;
+}
+
+template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks)
+{
+    { ProfScope p(c, KID_GEOM_COUNT); hipLaunchKernelGGL(k_geom_count<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
+    { ProfScope p(c, KID_SCAN_BLOCKS); hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, nblocks, g.cap, g.ntris, g.cnt); }
+    { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL(k_geom_emit<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
+    { ProfScope p(c, KID_GEOM_EMIT_CLIP);
+      uint32_t gb = (uint32_t)std::min<uint64_t>((g.ntris + 63) / 64, 1024);
+      hipLaunchKernelGGL(k_geom_emit_clip<VS>, dim3(gb), dim3(64), 0, c->stream, g, c->duni); }
+}
+
+template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uint32_t grid)
+{
+    ProfScope p(c, KID_RASTER);
+    hipLaunchKernelGGL((k_raster<K, PS>), dim3(grid), dim3(256), 0, c->stream, a, c->duni);
+}
+
+} // namespace
+
+extern "C" {
+
+int frr_abi_version(void) { return FRR_ABI_VERSION; }
+
+int frr_vs_input_floats(int vs_id)
+{
+    switch (vs_id) {
+    case FRR_VS_CLIP: return VSInfo<FRR_VS_CLIP>::NF;
+    case FRR_VS_CLIP_COLOR: return VSInfo<FRR_VS_CLIP_COLOR>::NF;
+    case FRR_VS_PHONG: return VSInfo<FRR_VS_PHONG>::NF;
+    case FRR_VS_GOURAUD: return VSInfo<FRR_VS_GOURAUD>::NF;
+    }
+    return FRR_ERR_INVALID;
+}
+int frr_vs_num_varyings(int vs_id)
+{
+    switch (vs_id) {
+    case FRR_VS_CLIP: return VSInfo<FRR_VS_CLIP>::K;
+    case FRR_VS_CLIP_COLOR: return VSInfo<FRR_VS_CLIP_COLOR>::K;
+    case FRR_VS_PHONG: return VSInfo<FRR_VS_PHONG>::K;
+    case FRR_VS_GOURAUD: return VSInfo<FRR_VS_GOURAUD>::K;
+    }
+    return FRR_ERR_INVALID;
+}
+
+const char *frr_last_error(const frr_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ctx **out)
+{
+    if (!out) return FRR_ERR_INVALID;
+    *out = nullptr;
+    if (width == 0 || height == 0 || (uint64_t)width * height > 0x3FFFFFFFull) return FRR_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FRR_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FRR_ERR_HIP;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FRR_ERR_HIP; // gfx950 code objects only
+    if (hipSetDevice(device) != hipSuccess) return FRR_ERR_HIP;
+    frr_ctx *c = new frr_ctx();
+    c->device = device; c->W = width; c->H = height;
+    if (stream) c->stream = (hipStream_t)stream;
+    else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FRR_ERR_HIP; } c->own_stream = true; }
+    const size_t npx = (size_t)width * height;
+    bool ok = hipMalloc((void **)&c->own_color, npx * 4) == hipSuccess && hipMalloc((void **)&c->own_depth, npx * 4) == hipSuccess &&
+              hipMalloc((void **)&c->own_tri_id, npx * 4) == hipSuccess && hipMalloc((void **)&c->cnt, sizeof(Counters)) == hipSuccess;
+    c->max_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    ok = ok && hipMalloc((void **)&c->tile_counts, (c->max_tiles + 1) * 4) == hipSuccess &&
+         hipMalloc((void **)&c->tile_offsets, (c->max_tiles + 1) * 4) == hipSuccess &&
+         hipMalloc((void **)&c->tile_cursor, (c->max_tiles + 1) * 4) == hipSuccess;
+    if (!ok) { frr_destroy(c); return FRR_ERR_NOMEM; }
+    c->color = c->own_color; c->depth = c->own_depth; c->tri_id = c->own_tri_id;
+    (void)hipMemsetAsync(c->cnt, 0, sizeof(Counters), c->stream);
+    (void)hipMemsetAsync(c->tile_counts, 0, (c->max_tiles + 1) * 4, c->stream);
+    (void)hipMemsetAsync(c->own_color, 0, npx * 4, c->stream);      // FrameBuffer::new zero-fills (renderer.rs:423)
+    (void)hipMemsetAsync(c->own_depth, 0, npx * 4, c->stream);
+    (void)hipMemsetAsync(c->own_tri_id, 0xFF, npx * 4, c->stream);
+    for (auto &e : c->ev) (void)hipEventCreate(&e);
+    memset(&c->uni, 0, sizeof c->uni);
+    frr_set_identity(c->uni.model); frr_set_identity(c->uni.view); frr_set_identity(c->uni.proj);
+    c->uni.light_pos[0] = 1.2f; c->uni.light_pos[1] = 1.0f; c->uni.light_pos[2] = 2.0f;   // phong.rs:129
+    c->uni.light_color[0] = c->uni.light_color[1] = c->uni.light_color[2] = 1.0f;         // phong.rs:128
+    c->uni.ambient_strength = 0.1f; c->uni.specular_strength = 0.5f;                      // phong.rs:131-132
+    c->uni.flat_color[0] = c->uni.flat_color[1] = c->uni.flat_color[2] = c->uni.flat_color[3] = 1.0f;
+    refresh_dev_uniforms(c);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { frr_destroy(c); return FRR_ERR_HIP; }
+    *out = c;
+    return FRR_OK;
+}
+
+void frr_destroy(frr_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
+    for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
+    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->clip_list, c->recs, c->vary,
+                    c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int frr_set_partition(frr_ctx *c, int rank, int world)
+{
+    if (!c || world < 1 || rank < 0 || rank >= world) return fail(c, FRR_ERR_INVALID, "bad partition");
+    c->rank = rank; c->world = world;
+    return FRR_OK;
+}
+int frr_set_count_fragments(frr_ctx *c, int) { return c ? FRR_OK : FRR_ERR_INVALID; } // always counted (one atomic per wave)
+
+int frr_bind_targets(frr_ctx *c, void *color, void *depth, void *tri_id)
+{
+    if (!c) return FRR_ERR_INVALID;
+    c->color = color ? (uint8_t *)color : c->own_color;
+    c->depth = depth ? (float *)depth : c->own_depth;
+    c->tri_id = tri_id ? (uint32_t *)tri_id : c->own_tri_id;
+    return FRR_OK;
+}
+int frr_target_ptrs(frr_ctx *c, void **color, void **depth, void **tri_id)
+{
+    if (!c) return FRR_ERR_INVALID;
+    if (color) *color = c->color;
+    if (depth) *depth = c->depth;
+    if (tri_id) *tri_id = c->tri_id;
+    return FRR_OK;
+}
+
+static int mesh_register(frr_ctx *c, const float *dev, bool owned, uint64_t ntris, int vs, int *mesh_out)
+{
+    Mesh m; m.dev = dev; m.owned = owned; m.used = true; m.ntris = ntris; m.vs = vs;
+    for (size_t i = 0; i < c->meshes.size(); ++i)
+        if (!c->meshes[i].used) { c->meshes[i] = m; *mesh_out = (int)i; return FRR_OK; }
+    c->meshes.push_back(m);
+    *mesh_out = (int)c->meshes.size() - 1;
+    return FRR_OK;
+}
+int frr_mesh_upload(frr_ctx *c, const float *vs_inputs, uint64_t ntris, int vs_id, int *mesh_out)
+{
+    if (!c || !mesh_out || frr_vs_input_floats(vs_id) < 0 || (ntris && !vs_inputs)) return fail(c, FRR_ERR_INVALID, "bad mesh");
+    if (ntris > 0x0FFFFFFFull) return fail(c, FRR_ERR_UNSUPPORTED, "more than 2^28 triangles per mesh");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t bytes = (size_t)ntris * 3 * frr_vs_input_floats(vs_id) * sizeof(float);
+    void *d = nullptr;
+    if (hipMalloc(&d, bytes ? bytes : 16) != hipSuccess) return fail(c, FRR_ERR_NOMEM, "hipMalloc mesh");
+    if (bytes) {
+        hipError_t e = hipMemcpyAsync(d, vs_inputs, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { (void)hipFree(d); return fail(c, FRR_ERR_HIP, hipGetErrorString(e)); }
+    }
+    return mesh_register(c, (const float *)d, true, ntris, vs_id, mesh_out);
+}
+int frr_mesh_bind_device(frr_ctx *c, const void *dev, uint64_t ntris, int vs_id, int *mesh_out)
+{
+    if (!c || !mesh_out || frr_vs_input_floats(vs_id) < 0 || (ntris && !dev)) return fail(c, FRR_ERR_INVALID, "bad mesh");
+    if (ntris > 0x0FFFFFFFull) return fail(c, FRR_ERR_UNSUPPORTED, "more than 2^28 triangles per mesh");
+    if (((uintptr_t)dev & 15u) != 0) return fail(c, FRR_ERR_INVALID, "mesh pointer must be 16-byte aligned");
+    return mesh_register(c, (const float *)dev, false, ntris, vs_id, mesh_out);
+}
+int frr_mesh_free(frr_ctx *c, int mesh)
+{
+    if (!c || mesh < 0 || mesh >= (int)c->meshes.size() || !c->meshes[mesh].used) return fail(c, FRR_ERR_INVALID, "bad mesh id");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->meshes[mesh].owned) (void)hipFree((void *)c->meshes[mesh].dev);
+    c->meshes[mesh] = Mesh();
+    return FRR_OK;
+}
+
+int frr_texture_upload(frr_ctx *c, int slot, const uint8_t *rgba, uint32_t w, uint32_t h)
+{
+    if (!c || slot < 0 || slot >= FRR_MAX_TEXTURES || !rgba || w == 0 || h == 0) return fail(c, FRR_ERR_INVALID, "bad texture");
+    if (h < w) return fail(c, FRR_ERR_UNSUPPORTED, "texture height < width: sample_2d clamps y with width (renderer.rs:523) and would index out of bounds");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    Texture &t = c->tex[slot];
+    if (t.dev) { (void)hipFree(t.dev); t.dev = nullptr; }
+    size_t bytes = (size_t)w * h * 4;
+    if (hipMalloc((void **)&t.dev, bytes) != hipSuccess) return fail(c, FRR_ERR_NOMEM, "hipMalloc texture");
+    HIP_TRY(c, hipMemcpyAsync(t.dev, rgba, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    t.w = w; t.h = h;
+    refresh_dev_uniforms(c);
+    return FRR_OK;
+}
+
+int frr_set_uniforms(frr_ctx *c, const frr_uniforms *u)
+{
+    if (!c || !u) return FRR_ERR_INVALID;
+    c->uni = *u;
+    refresh_dev_uniforms(c);
+    return FRR_OK;
+}
+
+int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
+{
+    if (!c || !rgba) return FRR_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t n = c->W * c->H, n4 = n / 4;
+    uint32_t packed;
+    memcpy(&packed, rgba, 4);
+    {
+        ProfScope p(c, KID_CLEAR);
+        uint32_t grid = std::min<uint32_t>((n4 + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_clear, dim3(grid ? grid : 1), dim3(256), 0, c->stream, (uint4 *)c->color, (uint4 *)c->depth,
+                           (uint4 *)c->tri_id, n4, packed, depth, c->cnt);
+        if (n4 * 4 < n)
+            hipLaunchKernelGGL(k_clear_tail, dim3(1), dim3(64), 0, c->stream, (uint32_t *)c->color, (uint32_t *)c->depth,
+                               c->tri_id, n4 * 4, n, packed, depth);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return FRR_OK;
+}
+
+int frr_geometry(frr_ctx *c, int mesh, uint64_t *ntris_setup)
+{
+    if (!c || mesh < 0 || mesh >= (int)c->meshes.size() || !c->meshes[mesh].used) return fail(c, FRR_ERR_INVALID, "bad mesh id");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const Mesh &m = c->meshes[mesh];
+    const int K = frr_vs_num_varyings(m.vs);
+    const uint64_t nt = m.ntris;
+    // worst case is 19 triangles out per triangle in (renderer.rs:150-171, 245-264)
+    uint64_t cap = nt <= (4u << 20) ? nt * FRR_MAX_OUT_TRIS : nt * 2 + 65536;
+    if (cap < c->setup_hint) cap = c->setup_hint;
+    if (cap < 1024) cap = 1024;
+    if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+    const uint32_t nblocks = (uint32_t)((nt + GEOM_BLOCK - 1) / GEOM_BLOCK);
+    int rc;
+    if ((rc = ensure(c, c->block_sums, c->block_sums_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
+    if ((rc = ensure(c, c->clip_list, c->clip_cap, (size_t)nt + 1)) != FRR_OK) return rc;
+    if ((rc = ensure(c, c->recs, c->setup_cap, (size_t)cap)) != FRR_OK) return rc;
+    if (K > 0 && (rc = ensure(c, c->vary, c->vary_cap, (size_t)c->setup_cap * 3 * 8 /* K <= 8 in the shader table */)) != FRR_OK) return rc;
+    GeomArgs g;
+    g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
+    g.cap = (uint32_t)std::min<size_t>(c->setup_cap, K > 0 ? c->vary_cap / (3 * (size_t)K) : c->setup_cap);
+    g.block_sums = c->block_sums; g.clip_list = c->clip_list; g.clip_cap = (uint32_t)c->clip_cap;
+    g.recs = c->recs; g.vary = c->vary; g.cnt = c->cnt;
+    if (nt == 0) {
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, 0u, g.cap, 0u, g.cnt);
+    } else {
+        switch (m.vs) {
+        case FRR_VS_CLIP: launch_geometry<FRR_VS_CLIP>(c, g, nblocks); break;
+        case FRR_VS_CLIP_COLOR: launch_geometry<FRR_VS_CLIP_COLOR>(c, g, nblocks); break;
+        case FRR_VS_PHONG: launch_geometry<FRR_VS_PHONG>(c, g, nblocks); break;
+        case FRR_VS_GOURAUD: launch_geometry<FRR_VS_GOURAUD>(c, g, nblocks); break;
+        }
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->geom_vs = m.vs; c->geom_ntris = nt;
+    if (ntris_setup) {
+        Counters h;
+        if ((rc = check_frame_counters(c, &h)) != FRR_OK) return rc;
+        *ntris_setup = h.n_setup;
+    }
+    return FRR_OK;
+}
+
+int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1)
+{
+    if (!c || c->geom_vs < 0) return fail(c, FRR_ERR_INVALID, "frr_raster before frr_geometry");
+    if (x0 > x1 || y0 > y1) return fail(c, FRR_ERR_INVALID, "range min > max (i32::clamp would panic, renderer.rs:285)");
+    const int64_t ww = (int64_t)x1 - x0, wh = (int64_t)y1 - y0;
+    if (ww > (int64_t)c->W || wh > (int64_t)c->H) return fail(c, FRR_ERR_INVALID, "window larger than the FrameBuffer");
+    if (ww > 0 && wh > 0 && (x1 <= 0 || (wh - 1) * (int64_t)x1 + ww > (int64_t)c->W * c->H))
+        return fail(c, FRR_ERR_INVALID, "depth index (cy-y0)*x1+(cx-x0) would leave the depth buffer (renderer.rs:362)");
+    const int K = frr_vs_num_varyings(c->geom_vs);
+    if ((ps_id == FRR_PS_COLOR && K != 3) || ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && K != 8) || ps_id < 0 || ps_id > FRR_PS_BLINN)
+        return fail(c, FRR_ERR_INVALID, "pixel shader does not match the vertex shader's varyings");
+    if ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && !c->duni.tex) return fail(c, FRR_ERR_INVALID, "no texture bound to uniforms.texture_slot");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (ww == 0 || wh == 0 || c->geom_ntris == 0) return FRR_OK;
+    RasterArgs a;
+    a.x0 = x0; a.x1 = x1; a.y0 = y0; a.y1 = y1; a.win_w = (int)ww; a.win_h = (int)wh;
+    a.cstride = (int)c->W; a.dstride = x1;
+    a.tiles_x = (int)((ww + TILE - 1) / TILE); a.tiles_y = (int)((wh + TILE - 1) / TILE);
+    a.rank = c->rank; a.world = c->world;
+    a.recs = c->recs; a.vary = c->vary;
+    a.tile_counts = c->tile_counts; a.tile_offsets = c->tile_offsets; a.tile_cursor = c->tile_cursor;
+    const uint32_t ntiles = (uint32_t)a.tiles_x * a.tiles_y;
+    int rc;
+    if (!c->bins) {
+        size_t want = std::max<size_t>((size_t)c->geom_ntris * 8 + 4 * (size_t)c->max_tiles, (size_t)1 << 22);
+        if ((rc = ensure(c, c->bins, c->bin_cap, want)) != FRR_OK) return rc;
+    }
+    a.bins = c->bins; a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xFFFFFFFFu);
+    a.color = c->color; a.depth = c->depth; a.tri_id = c->tri_id; a.cnt = c->cnt;
+    const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(c->geom_ntris * FRR_MAX_OUT_TRIS, c->setup_cap) + 255) / 256, 2048);
+    { ProfScope p(c, KID_BIN_COUNT); hipLaunchKernelGGL(k_bin<false>, dim3(bin_grid), dim3(256), 0, c->stream, a); }
+    { ProfScope p(c, KID_TILE_SCAN); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, a, ntiles); }
+    { ProfScope p(c, KID_BIN_FILL); hipLaunchKernelGGL(k_bin<true>, dim3(bin_grid), dim3(256), 0, c->stream, a); }
+    const int owned_rows = a.tiles_y > a.rank ? (a.tiles_y - a.rank + a.world - 1) / a.world : 0;
+    const uint32_t grid = (uint32_t)a.tiles_x * owned_rows;
+    if (grid) {
+        switch (ps_id) {
+        case FRR_PS_DEPTH: launch_raster<0, FRR_PS_DEPTH>(c, a, grid); break;
+        case FRR_PS_FLAT: launch_raster<0, FRR_PS_FLAT>(c, a, grid); break;
+        case FRR_PS_COLOR: launch_raster<3, FRR_PS_COLOR>(c, a, grid); break;
+        case FRR_PS_PHONG: launch_raster<8, FRR_PS_PHONG>(c, a, grid); break;
+        case FRR_PS_BLINN: launch_raster<8, FRR_PS_BLINN>(c, a, grid); break;
+        }
+    }
+    HIP_TRY(c, hipGetLastError());
+    return FRR_OK;
+}
+
+int frr_draw(frr_ctx *c, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1)
+{
+    int rc = frr_geometry(c, mesh, nullptr);
+    if (rc != FRR_OK) return rc;
+    return frr_raster(c, ps_id, x0, x1, y0, y1);
+}
+
+int frr_sync(frr_ctx *c)
+{
+    if (!c) return FRR_ERR_INVALID;
+    return check_frame_counters(c, nullptr);
+}
+
+int frr_readback(frr_ctx *c, uint8_t *rgba, float *depth, uint32_t *tri_id)
+{
+    if (!c) return FRR_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->W * c->H * 4;
+    if (rgba) HIP_TRY(c, hipMemcpyAsync(rgba, c->color, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (depth) HIP_TRY(c, hipMemcpyAsync(depth, c->depth, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (tri_id) HIP_TRY(c, hipMemcpyAsync(tri_id, c->tri_id, bytes, hipMemcpyDeviceToHost, c->stream));
+    return check_frame_counters(c, nullptr);
+}
+
+int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uint64_t *ntris)
+{
+    if (!c || !ntris || c->geom_vs < 0) return fail(c, FRR_ERR_INVALID, "no geometry to read back");
+    Counters h;
+    int rc = check_frame_counters(c, &h);
+    if (rc != FRR_OK) return rc;
+    *ntris = h.n_setup;
+    if (!out) return FRR_OK;
+    const uint64_t n = std::min<uint64_t>(h.n_setup, cap_tris);
+    const int K = frr_vs_num_varyings(c->geom_vs);
+    std::vector<RasterRec> recs(n);
+    std::vector<float> vary((size_t)n * 3 * K);
+    if (n) HIP_TRY(c, hipMemcpy(recs.data(), c->recs, n * sizeof(RasterRec), hipMemcpyDeviceToHost));
+    if (n && K) HIP_TRY(c, hipMemcpy(vary.data(), c->vary, vary.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) {
+        const RasterRec &r = recs[i];
+        const bool sw = r.flags & 1u;
+        for (int v = 0; v < 3; ++v) {
+            const int s = sw ? (v == 1 ? 2 : (v == 2 ? 1 : 0)) : v; // undo the orientation swap
+            frr_setup_vertex &o = out[i * 3 + v];
+            memset(&o, 0, sizeof o);
+            o.spf[0] = r.s[2 * s]; o.spf[1] = r.s[2 * s + 1];
+            o.spi[0] = r.p[2 * s]; o.spi[1] = r.p[2 * s + 1];
+            o.rhw = r.rhw[s];
+            for (int k = 0; k < K; ++k) o.ctx[k] = vary[(size_t)i * 3 * K + (size_t)s * K + k];
+        }
+    }
+    return FRR_OK;
+}
+
+int frr_get_stats(frr_ctx *c, frr_stats *out)
+{
+    if (!c || !out) return FRR_ERR_INVALID;
+    Counters h;
+    HIP_TRY(c, hipMemcpyAsync(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->tris_in = h.tris_in;
+    out->tris_setup = (uint64_t)h.tri_base + h.n_setup;
+    out->bin_entries = h.bin_entries_frame;
+    out->frag_covered = h.frag_covered;
+    out->frag_nan = h.frag_nan;
+    out->draws = h.draws;
+    out->overflow = h.overflow;
+    return FRR_OK;
+}
+
+int frr_event_record(frr_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= 16) return FRR_ERR_INVALID;
+    HIP_TRY(c, hipEventRecord(c->ev[slot], c->stream));
+    c->ev_set[slot] = true;
+    return FRR_OK;
+}
+int frr_event_elapsed_ms(frr_ctx *c, int a, int b, float *ms)
+{
+    if (!c || !ms || a < 0 || a >= 16 || b < 0 || b >= 16 || !c->ev_set[a] || !c->ev_set[b]) return FRR_ERR_INVALID;
+    HIP_TRY(c, hipEventSynchronize(c->ev[b]));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev[a], c->ev[b]));
+    return FRR_OK;
+}
+int frr_profile_enable(frr_ctx *c, int enable)
+{
+    if (!c) return FRR_ERR_INVALID;
+    prof_collect(c);
+    c->profiling = enable != 0;
+    return FRR_OK;
+}
+int frr_profile_reset(frr_ctx *c)
+{
+    if (!c) return FRR_ERR_INVALID;
+    prof_collect(c);
+    for (int i = 0; i < KID_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+    return FRR_OK;
+}
+int frr_profile_get(frr_ctx *c, const char *kernel, float *total_ms, uint32_t *launches)
+{
+    if (!c || !kernel) return FRR_ERR_INVALID;
+    prof_collect(c);
+    for (int i = 0; i < KID_COUNT; ++i)
+        if (strcmp(kernel, kKernelNames[i]) == 0) {
+            if (total_ms) *total_ms = (float)c->prof_ms[i];
+            if (launches) *launches = c->prof_n[i];
+            return FRR_OK;
+        }
+    return FRR_ERR_INVALID;
+}
+
+// ---- host helpers: matrix_util.rs:3-35 ------------------------------------------------------
+void frr_set_identity(float m[16])
+{
+    for (int i = 0; i < 16; ++i) m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+}
+static inline float h_dot3(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline void h_norm3(float *v) { float r = 1.0f / sqrtf(h_dot3(v, v)); v[0] *= r; v[1] *= r; v[2] *= r; }
+static inline void h_cross3(const float *a, const float *b, float *o)
+{
+    o[0] = a[1] * b[2] - b[1] * a[2]; o[1] = a[2] * b[0] - b[2] * a[0]; o[2] = a[0] * b[1] - b[0] * a[1];
+}
+void frr_set_look_at(const float eye[3], const float at[3], const float up[3], float m[16])
+{
+    float z[3] = {at[0] - eye[0], at[1] - eye[1], at[2] - eye[2]}, x[3], y[3];
+    h_norm3(z);                 // z_axis = (at - eye).normalize()      :11
+    h_cross3(up, z, x); h_norm3(x); // x_axis = up.cross(z_axis).normalize() :12
+    h_cross3(z, x, y);          // y_axis = z_axis.cross(x_axis)         :13
+    m[0] = x[0]; m[1] = y[0]; m[2] = z[0]; m[3] = 0.0f;
+    m[4] = x[1]; m[5] = y[1]; m[6] = z[1]; m[7] = 0.0f;
+    m[8] = x[2]; m[9] = y[2]; m[10] = z[2]; m[11] = 0.0f;
+    m[12] = -h_dot3(eye, x); m[13] = -h_dot3(eye, y); m[14] = -h_dot3(eye, z); m[15] = 1.0f;
+}
+void frr_set_perspective(float fovy, float aspect, float zn, float zf, float m[16])
+{
+    const float fax = 1.0f / tanf(fovy * 0.5f);         // f32::tan(..).recip()  :26
+    memset(m, 0, 16 * sizeof(float));
+    m[0] = fax / aspect;                                // :28
+    m[5] = fax;                                         // :29
+    m[10] = zf / (zf - zn);                             // :30
+    m[14] = -zn * zf / (zf - zn);                       // :31
+    m[11] = 1.0f;                                       // :32
+}
+
+// ---- debug hooks ------------------------------------------------------------------------------
+float frr_host_atan2f(float y, float x) { return fd_atan2f(y, x); }
+
+int frr_debug_atan2f(frr_ctx *c, const float *y, const float *x, float *out, uint64_t n)
+{
+    if (!c || !y || !x || !out) return FRR_ERR_INVALID;
+    if (n == 0) return FRR_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float *d = nullptr;
+    if (hipMalloc((void **)&d, n * 12) != hipSuccess) return fail(c, FRR_ERR_NOMEM, "hipMalloc");
+    hipError_t e = hipMemcpyAsync(d, y, n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + n, x, n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_atan2f, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d, d + n, d + 2 * n, n);
+        e = hipMemcpyAsync(out, d + 2 * n, n * 4, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, FRR_ERR_HIP, hipGetErrorString(e));
+    return FRR_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,346 @@
+// frr_device.h -- device-side data layout and the per-stage device functions of the gfx950
+// rasterization path.  Stage by stage this follows /root/reference/f_renderer/src/renderer.rs
+// (cited inline); the decomposition into kernels is new.
+#pragma once
+#include "../../include/frr.h"
+#include "frr_exact.h"
+
+namespace frr {
+
+constexpr int TILE = 32;          // screen tile edge in pixels (one workgroup, 8 KiB of LDS keys)
+constexpr int TILE_PX = TILE * TILE;
+constexpr int GEOM_BLOCK = 256;   // input triangles per geometry workgroup
+
+// ---- HBM layout ---------------------------------------------------------------------------
+// Setup triangle = what renderer.rs:387-394 `Vertex<T>` x3 carries into rasterization, split in
+// two arrays so the coverage/z loop touches exactly one 64-byte line per triangle:
+//   RasterRec[n]           64 B : post-orientation-swap (renderer.rs:309-312) vertex order
+//   varyings[n][3][K] f32       : same vertex order, read only by the resolve/shade step
+struct alignas(64) RasterRec {
+    int32_t p[6];    // spi: p0.x p0.y p1.x p1.y p2.x p2.y
+    float s[6];      // spf: same order
+    float rhw[3];
+    uint32_t flags;  // bit0: v1/v2 were swapped; bits1..3: edge 01,12,20 is NOT top-left (bias 1)
+};
+static_assert(sizeof(RasterRec) == 64, "one cache line per triangle");
+
+struct Counters {
+    uint32_t n_setup;       // setup triangles of the current draw
+    uint32_t n_clip;        // entries in the clip work list of the current draw
+    uint32_t tri_base;      // emission index of this draw's first triangle within the frame
+    uint32_t overflow;      // bit0 setup capacity, bit1 bin capacity, bit2 clip list
+    uint64_t bin_total;     // (triangle,tile) pairs of the current draw
+    uint64_t frag_covered;  // since last clear
+    uint64_t frag_nan;
+    uint64_t tris_in;
+    uint64_t bin_entries_frame;
+    uint32_t draws;
+    uint32_t need_setup;    // setup triangles the current draw needs (valid even on overflow)
+};
+
+struct DevUniforms {
+    float mvp[16];     // (proj*view)*model, phong.rs:119 hoisted (pure, so exact)
+    float model[16];
+    float view_pos[3];
+    float light_pos[3];
+    float light_color[3];
+    float ambient_strength, specular_strength;
+    float flat_color[4];
+    const uint8_t *tex;
+    uint32_t tex_w, tex_h;
+};
+
+struct GeomArgs {
+    const float *in;        // [ntris][3][NF]
+    uint32_t ntris;
+    uint32_t width, height; // viewport of renderer.rs:107-108
+    uint32_t cap;           // setup capacity (triangles)
+    uint32_t *block_sums;   // [nblocks], exclusive-scanned in place
+    uint2 *clip_list;       // (input index, output offset)
+    uint32_t clip_cap;
+    RasterRec *recs;
+    float *vary;
+    Counters *cnt;
+};
+
+struct RasterArgs {
+    int32_t x0, x1, y0, y1;           // width_range / height_range (renderer.rs:270-271)
+    int32_t win_w, win_h;             // x1-x0, y1-y0
+    int32_t cstride, dstride;         // colour row stride (fb.width), depth row stride (= x1, :362)
+    int32_t tiles_x, tiles_y;
+    int32_t rank, world;              // tile-row ownership (ty % world == rank)
+    const RasterRec *recs;
+    const float *vary;
+    uint32_t *tile_counts;            // [ntiles]
+    uint32_t *tile_offsets;           // [ntiles+1]
+    uint32_t *tile_cursor;            // [ntiles]
+    uint32_t *bins;
+    uint32_t bin_cap;
+    uint8_t *color;
+    float *depth;
+    uint32_t *tri_id;
+    Counters *cnt;
+};
+
+// ---- glam pieces used by the shader table -------------------------------------
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return (ax * bx + ay * by) + az * bz;
+}
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z)
+{
+    float r = 1.0f / sqrtf(dot3(x, y, z, x, y, z)); // Vec3::normalize = self * length_recip()
+    x = x * r; y = y * r; z = z * r;
+}
+__device__ __forceinline__ void mat4_mul_vec4(const float *m, float x, float y, float z, float w, float o[4])
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = ((m[r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w;
+}
+
+// ---- vertex shader table (contract renderer.rs:105,116) -----------------------------------
+template <int VS> struct VSInfo;
+template <> struct VSInfo<FRR_VS_CLIP> { static constexpr int NF = 4, K = 0; };
+template <> struct VSInfo<FRR_VS_CLIP_COLOR> { static constexpr int NF = 7, K = 3; };
+template <> struct VSInfo<FRR_VS_PHONG> { static constexpr int NF = 8, K = 8; };
+template <> struct VSInfo<FRR_VS_GOURAUD> { static constexpr int NF = 8, K = 3; };
+
+template <int VS, bool WITH_CTX>
+__device__ __forceinline__ void run_vs(const DevUniforms &u, const float *__restrict__ in, float pos[4], float *ctx)
+{
+    if constexpr (VS == FRR_VS_CLIP) {
+        float4 v = *reinterpret_cast<const float4 *>(in);
+        pos[0] = v.x; pos[1] = v.y; pos[2] = v.z; pos[3] = v.w;
+    } else if constexpr (VS == FRR_VS_CLIP_COLOR) {
+        pos[0] = in[0]; pos[1] = in[1]; pos[2] = in[2]; pos[3] = in[3];
+        if constexpr (WITH_CTX) { ctx[0] = in[4]; ctx[1] = in[5]; ctx[2] = in[6]; }
+    } else if constexpr (VS == FRR_VS_PHONG) {
+        float4 a = *reinterpret_cast<const float4 *>(in);      // pos.xyz, uv.x
+        float4 b = *reinterpret_cast<const float4 *>(in + 4);  // uv.y, normal.xyz
+        if constexpr (WITH_CTX) {
+            float w[4];
+            ctx[0] = a.w; ctx[1] = b.x;                        // phong.rs:120
+            ctx[2] = b.y; ctx[3] = b.z; ctx[4] = b.w;          // phong.rs:121-122
+            mat4_mul_vec4(u.model, a.x, a.y, a.z, 1.0f, w);    // phong.rs:123-124
+            ctx[5] = w[0]; ctx[6] = w[1]; ctx[7] = w[2];
+        }
+        mat4_mul_vec4(u.mvp, a.x, a.y, a.z, 1.0f, pos);        // phong.rs:125
+    } else { // FRR_VS_GOURAUD: per-vertex Lambert (no reference arithmetic; mirrors the oracle)
+        float4 a = *reinterpret_cast<const float4 *>(in);
+        float4 b = *reinterpret_cast<const float4 *>(in + 4);
+        if constexpr (WITH_CTX) {
+            float w[4];
+            mat4_mul_vec4(u.model, a.x, a.y, a.z, 1.0f, w);
+            float nx = b.y, ny = b.z, nz = b.w;
+            normalize3(nx, ny, nz);
+            float lx = u.light_pos[0] - w[0], ly = u.light_pos[1] - w[1], lz = u.light_pos[2] - w[2];
+            normalize3(lx, ly, lz);
+            float diff = f32_max(dot3(nx, ny, nz, lx, ly, lz), 0.0f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                ctx[k] = u.light_color[k] * u.ambient_strength + diff * u.light_color[k];
+        }
+        mat4_mul_vec4(u.mvp, a.x, a.y, a.z, 1.0f, pos);
+    }
+}
+
+// ---- clip classification (renderer.rs:46-73, 123-174) -------------------------------------
+// plane order [X_LEFT, X_RIGHT, Y_UP, Y_DOWN, Z_NEAR, Z_FAR] (renderer.rs:123-131)
+__device__ __forceinline__ uint32_t inside_bits(const float p[4])
+{
+    float w = p[3];
+    uint32_t b = 0;
+    b |= (p[0] >= -w) ? 1u : 0u;
+    b |= (p[0] <= w) ? 2u : 0u;
+    b |= (p[1] <= w) ? 4u : 0u;
+    b |= (p[1] >= -w) ? 8u : 0u;
+    b |= (p[2] >= 0.0f) ? 16u : 0u;
+    b |= (p[2] <= w) ? 32u : 0u;
+    return b;
+}
+__device__ __forceinline__ float intersect_ratio(int plane, const float a[4], const float b[4])
+{
+    float a_w = a[3], b_w = b[3];
+    switch (plane) {
+    case 0: return -(a[0] + a_w) / (b_w + b[0] - a[0] - a_w);   // X_LEFT  :65
+    case 1: return (a_w - a[0]) / (a_w - b_w - a[0] + b[0]);    // X_RIGHT :66
+    case 2: return (a_w - a[1]) / (a_w - b_w - a[1] + b[1]);    // Y_UP    :67
+    case 3: return -(a[1] + a_w) / (b_w + b[1] - a_w - a[1]);   // Y_DOWN  :68
+    case 4: return a_w / (a_w - b_w);                           // Z_NEAR  :70 (sic)
+    default: return (a_w - a[2]) / (a_w - b_w - a[2] + b[2]);   // Z_FAR   :69
+    }
+}
+constexpr float CLIP_EPSILON = 1.0e-5f; // renderer.rs:44
+
+// Number of triangles geometry_processing returns for clip positions pos[3][4]:
+// 0 (None, :117-119), 1 (all inside), else n-2 with n = 3 + kept intersections (:150-171).
+// `clipped` tells the caller the slow path is needed.
+__device__ __forceinline__ uint32_t classify(const float pos[3][4], bool &clipped)
+{
+    clipped = false;
+    if (pos[0][3] == 0.0f || pos[1][3] == 0.0f || pos[2][3] == 0.0f) return 0;
+    uint32_t in0 = inside_bits(pos[0]), in1 = inside_bits(pos[1]), in2 = inside_bits(pos[2]);
+    if ((in0 & in1 & in2) == 63u) return 1;
+    clipped = true;
+    uint32_t n = 3;
+    const uint32_t inb[3] = {in0, in1, in2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 3; ++j) {
+            uint32_t diff = inb[i] ^ inb[j];
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+                if (diff & (1u << p)) {
+                    float t = intersect_ratio(p, pos[i], pos[j]);
+                    float w = pos[i][3] + t * (pos[j][3] - pos[i][3]);  // :89, w lane
+                    if (fabsf(w) > CLIP_EPSILON) ++n;                   // :164
+                }
+        }
+    return n - 2;
+}
+
+// renderer.rs:220-235 for one vertex
+struct ScreenVtx { float rhw, ndcx, ndcy, sx, sy; int32_t ix, iy; };
+__device__ __forceinline__ ScreenVtx to_screen(const float pos[4], float fw, float fh)
+{
+    ScreenVtx v;
+    v.rhw = 1.0f / pos[3];
+    v.ndcx = pos[0] * v.rhw;
+    v.ndcy = pos[1] * v.rhw;
+    v.sx = (v.ndcx + 1.0f) * fw * 0.5f;
+    v.sy = (1.0f - v.ndcy) * fh * 0.5f;
+    v.ix = f32_as_i32(v.sx + 0.5f);
+    v.iy = f32_as_i32(v.sy + 0.5f);
+    return v;
+}
+// renderer.rs:26-29
+__device__ __forceinline__ bool is_top_left(int ax, int ay, int bx, int by)
+{
+    return ((ay == by) && (ax < bx)) || (ay > by);
+}
+
+// Orientation (renderer.rs:300-312) + top-left flags (:318-320) + record store, for one emitted
+// triangle whose vertices v0,v1,v2 are in emission order.
+template <int K>
+__device__ __forceinline__ void store_setup(RasterRec *__restrict__ recs, float *__restrict__ vary, uint32_t idx,
+                                            const ScreenVtx &v0, ScreenVtx v1, ScreenVtx v2, const float *c0,
+                                            const float *c1, const float *c2)
+{
+    float v01x = v1.ndcx - v0.ndcx, v01y = v1.ndcy - v0.ndcy;
+    float v02x = v2.ndcx - v0.ndcx, v02y = v2.ndcy - v0.ndcy;
+    float nz = v01x * v02y - v02x * v01y;
+    bool swap = nz > 0.0f;
+    if (swap) { ScreenVtx t = v1; v1 = v2; v2 = t; const float *tc = c1; c1 = c2; c2 = tc; }
+    uint32_t flags = swap ? 1u : 0u;
+    flags |= is_top_left(v0.ix, v0.iy, v1.ix, v1.iy) ? 0u : 2u;
+    flags |= is_top_left(v1.ix, v1.iy, v2.ix, v2.iy) ? 0u : 4u;
+    flags |= is_top_left(v2.ix, v2.iy, v0.ix, v0.iy) ? 0u : 8u;
+    uint4 *dst = reinterpret_cast<uint4 *>(recs + idx);
+    dst[0] = make_uint4((uint32_t)v0.ix, (uint32_t)v0.iy, (uint32_t)v1.ix, (uint32_t)v1.iy);
+    dst[1] = make_uint4((uint32_t)v2.ix, (uint32_t)v2.iy, f2u(v0.sx), f2u(v0.sy));
+    dst[2] = make_uint4(f2u(v1.sx), f2u(v1.sy), f2u(v2.sx), f2u(v2.sy));
+    dst[3] = make_uint4(f2u(v0.rhw), f2u(v1.rhw), f2u(v2.rhw), flags);
+    if constexpr (K > 0) {
+        float *o = vary + (size_t)idx * (3 * K);
+#pragma unroll
+        for (int k = 0; k < K; ++k) { o[k] = c0[k]; o[K + k] = c1[k]; o[2 * K + k] = c2[k]; }
+    }
+}
+
+// ---- fragment arithmetic (renderer.rs:343-360), shared by the coverage loop and the resolve --
+struct Frag { float a, b, c, rhw; bool valid; };
+__device__ __forceinline__ Frag frag_eval(float s0x_, float s0y_, float s1x_, float s1y_, float s2x_, float s2y_,
+                                          float r0, float r1, float r2, int cx, int cy)
+{
+    Frag f;
+    float pxx = (float)cx + 0.5f, pxy = (float)cy + 0.5f;          // :325
+    float s0x = s0x_ - pxx, s0y = s0y_ - pxy;                      // :343-345
+    float s1x = s1x_ - pxx, s1y = s1y_ - pxy;
+    float s2x = s2x_ - pxx, s2y = s2y_ - pxy;
+    float a = fabsf(s1x * s2y - s1y * s2x);                        // :347-349
+    float b = fabsf(s2x * s0y - s2y * s0x);
+    float c = fabsf(s0x * s1y - s0y * s1x);
+    float s = a + b + c;                                           // :351
+    f.valid = !(s == 0.0f);                                        // :352-354
+    float inv = 1.0f / s;                                          // :356-358
+    f.a = a * inv; f.b = b * inv; f.c = c * inv;
+    f.rhw = r0 * f.a + r1 * f.b + r2 * f.c;                        // :360
+    return f;
+}
+
+// ---- pixel shader table (contract renderer.rs:283,380) ----------------------------------
+// FrameBuffer::sample_2d renderer.rs:516-538 (+ get_pixel :505-514, u8_array_to_vec4 :16-24)
+__device__ __forceinline__ void sample_2d(const DevUniforms &u, float uu, float vv, float out[4])
+{
+    float x = uu * (float)u.tex_w;
+    float y = vv * (float)u.tex_h;
+    float a = x - truncf(x);
+    float b = y - truncf(y);
+    uint32_t wm1 = u.tex_w - 1u;
+    uint32_t x1 = min(f32_as_u32(x), wm1);
+    uint32_t y1 = min(f32_as_u32(y), wm1); // sic: width (:523)
+    uint32_t x2 = min(x1 + 1u, wm1);
+    uint32_t y2 = min(y1 + 1u, wm1);       // sic: width (:525)
+    const uchar4 *t = reinterpret_cast<const uchar4 *>(u.tex);
+    uchar4 q11 = t[y1 * u.tex_w + x1], q12 = t[y2 * u.tex_w + x1];
+    uchar4 q21 = t[y1 * u.tex_w + x2], q22 = t[y2 * u.tex_w + x2];
+    float oma = 1.0f - a, omb = 1.0f - b;
+    const uint8_t *p11 = reinterpret_cast<const uint8_t *>(&q11), *p12 = reinterpret_cast<const uint8_t *>(&q12);
+    const uint8_t *p21 = reinterpret_cast<const uint8_t *>(&q21), *p22 = reinterpret_cast<const uint8_t *>(&q22);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float c11 = ((float)p11[k] / 255.0f) * oma * omb;
+        float c12 = ((float)p12[k] / 255.0f) * oma * b;
+        float c21 = ((float)p21[k] / 255.0f) * a * omb;
+        float c22 = ((float)p22[k] / 255.0f) * a * b;
+        out[k] = c11 + c12 + c21 + c22;
+    }
+}
+
+template <int PS>
+__device__ __forceinline__ void run_ps(const DevUniforms &u, const float *ctx, float out[4])
+{
+    if constexpr (PS == FRR_PS_FLAT) {
+        out[0] = u.flat_color[0]; out[1] = u.flat_color[1]; out[2] = u.flat_color[2]; out[3] = u.flat_color[3];
+    } else if constexpr (PS == FRR_PS_COLOR) {
+        out[0] = ctx[0]; out[1] = ctx[1]; out[2] = ctx[2]; out[3] = 1.0f;
+    } else if constexpr (PS == FRR_PS_PHONG || PS == FRR_PS_BLINN) {
+        float amb[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) amb[k] = u.light_color[k] * u.ambient_strength;       // phong.rs:134
+        float nx = ctx[2], ny = ctx[3], nz = ctx[4];
+        normalize3(nx, ny, nz);                                                           // :136
+        float lx = u.light_pos[0] - ctx[5], ly = u.light_pos[1] - ctx[6], lz = u.light_pos[2] - ctx[7];
+        normalize3(lx, ly, lz);                                                           // :137
+        float diff = f32_max(dot3(nx, ny, nz, lx, ly, lz), 0.0f);                         // :138
+        float vx = u.view_pos[0] - ctx[5], vy = u.view_pos[1] - ctx[6], vz = u.view_pos[2] - ctx[7];
+        normalize3(vx, vy, vz);                                                           // :141
+        float s;
+        if constexpr (PS == FRR_PS_PHONG) {
+            float Lx = -lx, Ly = -ly, Lz = -lz;                                           // :142
+            float t = 2.0f * dot3(Lx, Ly, Lz, nx, ny, nz);                                // vector_util.rs:6
+            float rx = t * nx - Lx, ry = t * ny - Ly, rz = t * nz - Lz;
+            normalize3(rx, ry, rz);
+            s = f32_max(dot3(vx, vy, vz, rx, ry, rz), 0.0f);                              // :143
+        } else {
+            float hx = lx + vx, hy = ly + vy, hz = lz + vz;
+            normalize3(hx, hy, hz);
+            s = f32_max(dot3(nx, ny, nz, hx, hy, hz), 0.0f);
+        }
+        s = s * s; s = s * s; s = s * s; s = s * s; s = s * s;                            // powi(32)
+        float tex[4];
+        sample_2d(u, ctx[0], ctx[1], tex);                                                // :146-151
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float diffuse = diff * u.light_color[k];                                      // :139
+            float spec = u.specular_strength * s * u.light_color[k];                      // :144
+            out[k] = tex[k] * (amb[k] + diffuse + spec);                                  // :153
+        }
+        out[3] = tex[3] * 1.0f;
+    } else {
+        out[0] = out[1] = out[2] = out[3] = 0.0f;
+    }
+}
+
+} // namespace frr

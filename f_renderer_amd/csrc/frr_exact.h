@@ -1,0 +1,173 @@
+// frr_exact.h -- scalar helpers that reproduce Rust / glibc fp32 semantics bit for bit on gfx950.
+//
+// The whole library is compiled with -ffp-contract=off (no FMA contraction), default IEEE
+// division/sqrt (-fhip-fp32-correctly-rounded-divide-sqrt, hipcc default) and fp32 denormals
+// preserved (hipcc default), so `a*b+c` below means two roundings exactly as in the reference
+// (/root/reference/f_renderer/src/renderer.rs; Rust never contracts or reassociates).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FRR_HD __host__ __device__ __forceinline__
+
+namespace frr {
+
+FRR_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+FRR_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// Rust `f32 as i32`: truncate, saturate, NaN -> 0  (used at renderer.rs:233-234)
+FRR_HD int32_t f32_as_i32(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)f;
+}
+// Rust `f32 as u32`  (renderer.rs:522-523)
+FRR_HD uint32_t f32_as_u32(float f)
+{
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+// Rust `f32 as u8` after f32::clamp(0,255) (renderer.rs:9-12): NaN -> 0
+FRR_HD uint32_t quantize_u8(float v)
+{
+    float x = v * 255.0f;
+    if (x < 0.0f) x = 0.0f;
+    if (x > 255.0f) x = 255.0f;
+    if (!(x > 0.0f)) return 0u;
+    return (uint32_t)x; // x in (0,255]
+}
+// f32::max: NaN operand yields the other
+FRR_HD float f32_max(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    return a > b ? a : b;
+}
+// f32::total_cmp as a signed sortable key (renderer.rs:217)
+FRR_HD int32_t total_order_key(float f)
+{
+    int32_t i = (int32_t)f2u(f);
+    i ^= (int32_t)(((uint32_t)(i >> 31)) >> 1);
+    return i;
+}
+// Monotone map f32 -> u32 for the `rhw < depth` test (renderer.rs:363): a < b  <=>  zkey(a) < zkey(b)
+// for all non-NaN a,b, with -0.0 and +0.0 mapped to the same key (they compare equal).
+FRR_HD uint32_t zkey(float f)
+{
+    uint32_t u = f2u(f);
+    if ((u << 1) == 0u) return 0x80000000u; // +-0
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+FRR_HD float zkey_decode(uint32_t k)
+{
+    return u2f((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// ---------------------------------------------------------------------------------------------
+// atan2f: renderer.rs:208-209 calls f32::atan2, i.e. the platform libm.  This is a port of the
+// fdlibm-derived float algorithm glibc 2.35 ships (sysdeps/ieee754/flt-32/e_atan2f.c, s_atanf.c:
+// argument reduction to 4 breakpoints + an 11-term odd/even split polynomial), written from the
+// published algorithm; it uses only fp32 + - * / so it rounds identically on host and device.
+// tests/test_atan2f.py pins it against the container's glibc atan2f (exhaustive atanf sweep +
+// random/structured atan2f pairs).
+// ---------------------------------------------------------------------------------------------
+FRR_HD float fd_atanf(float x)
+{
+    const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
+                aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
+                aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f,
+                aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    int32_t hx = (int32_t)f2u(x);
+    int32_t ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) { // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x; // NaN
+        float r = atanhi[3] + atanlo[3];
+        return hx > 0 ? r : -r;
+    }
+    if (ix < 0x3ee00000) {       // |x| < 0.4375
+        if (ix < 0x31000000) return x; // |x| < 2^-29
+        id = -1;
+    } else {
+        x = u2f((uint32_t)ix); // fabsf
+        if (ix < 0x3f980000) {   // |x| < 1.1875
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else                 { id = 1; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else                 { id = 3; x = -1.0f / x; }
+        }
+    }
+    float z = x * x;
+    float w = z * z;
+    float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    float hi = id == 0 ? atanhi[0] : id == 1 ? atanhi[1] : id == 2 ? atanhi[2] : atanhi[3];
+    float lo = id == 0 ? atanlo[0] : id == 1 ? atanlo[1] : id == 2 ? atanlo[2] : atanlo[3];
+    z = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -z : z;
+}
+
+FRR_HD float fd_atan2f(float y, float x)
+{
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f,
+                pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
+    int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y; // NaN
+    if (hx == 0x3f800000) return fd_atanf(y);             // x == 1.0
+    int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);          // 2*sign(x) + sign(y)
+    if (iy == 0) {
+        switch (m) {
+        case 0: case 1: return y;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) {
+            case 0: return pi_o_4 + tiny;
+            case 1: return -pi_o_4 - tiny;
+            case 2: return 3.0f * pi_o_4 + tiny;
+            default: return -3.0f * pi_o_4 - tiny;
+            }
+        } else {
+            switch (m) {
+            case 0: return 0.0f;
+            case 1: return -0.0f;
+            case 2: return pi + tiny;
+            default: return -pi - tiny;
+            }
+        }
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    int32_t k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = fd_atanf(u2f(f2u(y / x) & 0x7fffffffu));
+    switch (m) {
+    case 0: return z;
+    case 1: return u2f(f2u(z) ^ 0x80000000u);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+
+// sort angle of renderer.rs:205-216: atan2 mapped to [0, 2pi)
+FRR_HD float sort_angle(float fy, float fx)
+{
+    float a = fd_atan2f(fy, fx);
+    if (a < 0.0f) a += 3.14159274101257324f * 2.0f;
+    return a;
+}
+
+} // namespace frr

@@ -1,0 +1,480 @@
+// frr_kernels.h -- the gfx950 kernels of the rasterization path (wave64, LDS-tiled).
+//
+// Frame = clear -> per draw { geometry: count, scan, emit, emit_clip ; binning: count, scan, fill ;
+// raster+resolve per 32x32 screen tile }.  See DESIGN.md for the roofline of each kernel.
+#pragma once
+#include "frr_device.h"
+
+namespace frr {
+
+// ---------------------------------------------------------------------------------------------
+// K0 clear: FrameBuffer::fill (renderer.rs:485-494) + depth_buffer.fill (phong.rs:317) + ids.
+// 16 B per lane streaming stores.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_clear(uint4 *__restrict__ color, uint4 *__restrict__ depth,
+                                               uint4 *__restrict__ ids, uint32_t n4, uint32_t rgba, float d,
+                                               Counters *cnt)
+{
+    const uint32_t db = f2u(d);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+        color[i] = make_uint4(rgba, rgba, rgba, rgba);
+        depth[i] = make_uint4(db, db, db, db);
+        ids[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        cnt->n_setup = 0; cnt->n_clip = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
+        cnt->frag_covered = 0; cnt->frag_nan = 0; cnt->tris_in = 0; cnt->bin_entries_frame = 0; cnt->draws = 0;
+    }
+}
+// tail elements when W*H is not a multiple of 4
+__global__ void k_clear_tail(uint32_t *color, uint32_t *depth, uint32_t *ids, uint32_t from, uint32_t n,
+                             uint32_t rgba, float d)
+{
+    uint32_t i = from + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { color[i] = rgba; depth[i] = f2u(d); ids[i] = ~0u; }
+}
+
+// ---- block-level helpers -------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+// exclusive scan of one value per thread over a 256-thread block; returns block total via `total`
+__device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t *s_w /*[4]*/, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    uint32_t base = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
+    total = w0 + w1 + w2 + w3;
+    return base + inc - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1a geometry count: VS x3 + classification (renderer.rs:113-174) -> triangles per input,
+// reduced per 256-triangle block.  HBM: reads the input triangles once.
+// ---------------------------------------------------------------------------------------------
+template <int VS>
+__global__ __launch_bounds__(GEOM_BLOCK) void k_geom_count(GeomArgs g, DevUniforms u)
+{
+    __shared__ uint32_t s_w[4];
+    constexpr int NF = VSInfo<VS>::NF;
+    const uint32_t t = blockIdx.x * GEOM_BLOCK + threadIdx.x;
+    uint32_t n = 0;
+    if (t < g.ntris) {
+        float pos[3][4];
+        const float *in = g.in + (size_t)t * (3 * NF);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) run_vs<VS, false>(u, in + v * NF, pos[v], nullptr);
+        bool clipped;
+        n = classify(pos, clipped);
+    }
+    uint32_t total;
+    block_excl_scan256(n, s_w, total);
+    if (threadIdx.x == 0) g.block_sums[blockIdx.x] = total;
+}
+
+// K1b: exclusive scan of the block sums (single workgroup), publishes n_setup, advances tri_base.
+__global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *__restrict__ sums, uint32_t nblocks, uint32_t cap,
+                                                      uint32_t ntris, Counters *cnt)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < nblocks ? sums[i] : 0u;
+        uint32_t inc = wave_incl_scan(v);
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { uint32_t x = s_w[k]; if (k < w) wbase += x; tot += x; }
+        uint32_t carry = s_carry;
+        if (i < nblocks) sums[i] = carry + wbase + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        uint32_t total = s_carry;
+        cnt->tri_base += cnt->n_setup; // previous draw's triangles precede this draw's in the frame
+        cnt->need_setup = total;
+        if (total > cap) { cnt->overflow |= 1u; total = 0; }
+        cnt->n_setup = total;
+        cnt->n_clip = 0;
+        cnt->tris_in += ntris;
+        cnt->draws += 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1c geometry emit, unclipped fast path: renderer.rs:113-148 (VS, reject, classify),
+// :180-218 (centroid + stable angle sort of 3), :220-235 (divide, viewport, snap), :237-243,
+// then the per-triangle prologue of rasterization (:300-320) so the record is ready to scan.
+// Clipped triangles only reserve their output range and go to the clip work list.
+// ---------------------------------------------------------------------------------------------
+template <int VS>
+__global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniforms u)
+{
+    __shared__ uint32_t s_w[4];
+    constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K;
+    const uint32_t t = blockIdx.x * GEOM_BLOCK + threadIdx.x;
+    float pos[3][4];
+    float ctx[3][K > 0 ? K : 1];
+    uint32_t n = 0;
+    bool clipped = false;
+    if (t < g.ntris) {
+        const float *in = g.in + (size_t)t * (3 * NF);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
+        n = classify(pos, clipped);
+    }
+    uint32_t total;
+    const uint32_t off = g.block_sums[blockIdx.x] + block_excl_scan256(n, s_w, total);
+    if (n == 0 || g.cnt->n_setup == 0) return; // n_setup == 0: nothing to emit or capacity overflow
+    if (clipped) {
+        uint32_t slot = atomicAdd(&g.cnt->n_clip, 1u);
+        if (slot < g.clip_cap) g.clip_list[slot] = make_uint2(t, off);
+        else atomicOr(&g.cnt->overflow, 4u);
+        return;
+    }
+    // centroid (:180-187), n == 3
+    float cx = 0.0f, cy = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) { cx += pos[v][0]; cy += pos[v][1]; }
+    const float inv_n = 1.0f / 3.0f;
+    cx *= inv_n; cy *= inv_n;
+    int32_t key[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) key[v] = total_order_key(sort_angle(pos[v][1] - cy, pos[v][0] - cx));
+    // stable rank of each vertex (:205-218)
+    int r0 = (key[1] < key[0]) + (key[2] < key[0]);
+    int r1 = (key[0] <= key[1]) + (key[2] < key[1]);
+    // (the third rank is implied by the other two)
+    const float fw = (float)g.width, fh = (float)g.height;
+    ScreenVtx s0 = to_screen(pos[0], fw, fh), s1 = to_screen(pos[1], fw, fh), s2 = to_screen(pos[2], fw, fh);
+    // vertex with rank r
+    auto pick = [&](int r) { return r0 == r ? s0 : (r1 == r ? s1 : s2); };
+    ScreenVtx a = pick(0), b = pick(1), c = pick(2);
+    float ca[K > 0 ? K : 1], cb[K > 0 ? K : 1], cc[K > 0 ? K : 1];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        ca[k] = r0 == 0 ? ctx[0][k] : (r1 == 0 ? ctx[1][k] : ctx[2][k]);
+        cb[k] = r0 == 1 ? ctx[0][k] : (r1 == 1 ? ctx[1][k] : ctx[2][k]);
+        cc[k] = r0 == 2 ? ctx[0][k] : (r1 == 2 ? ctx[1][k] : ctx[2][k]);
+    }
+    store_setup<K>(g.recs, g.vary, off, a, b, c, ca, cb, cc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1d geometry emit, clipped slow path: the reference's quirky clipper reproduced as is
+// (renderer.rs:150-171: one intersection per (edge, plane) with differing in/out flags, outside
+// vertices kept), centroid + stable angle sort of up to 21 vertices (:180-218), fan (:245-266).
+// One lane per clipped triangle, grid-stride over the work list; vertex list in scratch.
+// ---------------------------------------------------------------------------------------------
+template <int VS>
+__global__ __launch_bounds__(64) void k_geom_emit_clip(GeomArgs g, DevUniforms u)
+{
+    constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K, KS = K > 0 ? K : 1;
+    const uint32_t nclip = min(g.cnt->n_clip, g.clip_cap);
+    for (uint32_t e = blockIdx.x * 64 + threadIdx.x; e < nclip; e += gridDim.x * 64) {
+        const uint2 item = g.clip_list[e];
+        const float *in = g.in + (size_t)item.x * (3 * NF);
+        float vpos[21][4];
+        float vctx[21][KS];
+        float pos[3][4], ctx[3][KS];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
+        uint32_t inb[3] = {inside_bits(pos[0]), inside_bits(pos[1]), inside_bits(pos[2])};
+        int n = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = i + 1; j < 3; ++j) {
+                uint32_t diff = inb[i] ^ inb[j];
+                for (int p = 0; p < 6; ++p)
+                    if (diff & (1u << p)) {
+                        float t = intersect_ratio(p, pos[i], pos[j]);
+                        float np[4];
+                        for (int k = 0; k < 4; ++k) np[k] = pos[i][k] + t * (pos[j][k] - pos[i][k]); // :89
+                        if (fabsf(np[3]) > CLIP_EPSILON) {                                          // :164
+                            for (int k = 0; k < 4; ++k) vpos[n][k] = np[k];
+                            for (int k = 0; k < K; ++k) vctx[n][k] = ctx[i][k] + (ctx[j][k] - ctx[i][k]) * t; // :91
+                            ++n;
+                        }
+                    }
+            }
+        for (int v = 0; v < 3; ++v) {                                                               // :171
+            for (int k = 0; k < 4; ++k) vpos[n][k] = pos[v][k];
+            for (int k = 0; k < K; ++k) vctx[n][k] = ctx[v][k];
+            ++n;
+        }
+        float cx = 0.0f, cy = 0.0f;                                                                 // :180-187
+        for (int i = 0; i < n; ++i) { cx += vpos[i][0]; cy += vpos[i][1]; }
+        float inv_n = 1.0f / (float)n;
+        cx *= inv_n; cy *= inv_n;
+        int32_t key[21];
+        int ord[21];
+        for (int i = 0; i < n; ++i) {
+            key[i] = total_order_key(sort_angle(vpos[i][1] - cy, vpos[i][0] - cx));
+            ord[i] = i;
+        }
+        for (int i = 1; i < n; ++i) { // stable insertion sort on (key, ord)
+            int32_t tk = key[i];
+            int to = ord[i];
+            int j = i - 1;
+            while (j >= 0 && key[j] > tk) { key[j + 1] = key[j]; ord[j + 1] = ord[j]; --j; }
+            key[j + 1] = tk; ord[j + 1] = to;
+        }
+        const float fw = (float)g.width, fh = (float)g.height;
+        auto emit = [&](uint32_t idx, int i0, int i1, int i2) {
+            const int a = ord[i0], b = ord[i1], c = ord[i2];
+            ScreenVtx sa = to_screen(vpos[a], fw, fh), sb = to_screen(vpos[b], fw, fh), sc = to_screen(vpos[c], fw, fh);
+            store_setup<K>(g.recs, g.vary, idx, sa, sb, sc, vctx[a], vctx[b], vctx[c]);
+        };
+        uint32_t idx = item.y;
+        if (n == 3) { emit(idx, 0, 1, 2); continue; }       // :237-243 (cannot happen for clipped, kept)
+        int last = n - 1;                                   // :245-266
+        while (last > 3) { emit(idx++, 0, last - 1, last); --last; }
+        emit(idx++, 0, 2, 3);
+        emit(idx++, 0, 1, 2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 binning.  A setup triangle goes into every OWNED 32x32 tile its clamped bbox
+// (renderer.rs:285-298) touches.  Small footprints are handled per lane; a triangle touching
+// more than BIN_COOP tiles is spread over the 64 lanes of its wave.
+// ---------------------------------------------------------------------------------------------
+constexpr int BIN_COOP = 6;
+
+struct TileRange { int tx0, tx1, ty0, ty1; }; // inclusive-exclusive tile ranges (window-local)
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+__device__ __forceinline__ TileRange tri_tiles(const RasterArgs &a, const RasterRec *__restrict__ r)
+{
+    const int4 q0 = *reinterpret_cast<const int4 *>(r);       // p0.x p0.y p1.x p1.y
+    const int2 q1 = *reinterpret_cast<const int2 *>(&r->p[4]); // p2.x p2.y
+    int minx = clampi(min(q0.x, min(q0.z, q1.x)), a.x0, a.x1), maxx = clampi(max(q0.x, max(q0.z, q1.x)), a.x0, a.x1);
+    int miny = clampi(min(q0.y, min(q0.w, q1.y)), a.y0, a.y1), maxy = clampi(max(q0.y, max(q0.w, q1.y)), a.y0, a.y1);
+    TileRange t;
+    if (maxx <= minx || maxy <= miny) { t.tx0 = t.tx1 = t.ty0 = t.ty1 = 0; return t; }
+    t.tx0 = (minx - a.x0) / TILE; t.tx1 = (maxx - 1 - a.x0) / TILE + 1;
+    t.ty0 = (miny - a.y0) / TILE; t.ty1 = (maxy - 1 - a.y0) / TILE + 1;
+    return t;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bin(RasterArgs a)
+{
+    const uint32_t n = a.cnt->n_setup;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * 4u;
+    for (uint32_t base = wave * 64u; base < n; base += nwaves * 64u) {
+        const uint32_t i = base + lane;
+        TileRange t = {0, 0, 0, 0};
+        if (i < n) t = tri_tiles(a, a.recs + i);
+        const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
+        const int nt = ntx * nty;
+        auto visit = [&](uint32_t tri, int tx, int ty) {
+            if (ty % a.world != a.rank) return;
+            const int tile = ty * a.tiles_x + tx;
+            if constexpr (FILL) {
+                uint32_t pos = a.tile_offsets[tile] + atomicAdd(&a.tile_cursor[tile], 1u);
+                if (pos < a.bin_cap) a.bins[pos] = tri;
+            } else {
+                atomicAdd(&a.tile_counts[tile], 1u);
+            }
+        };
+        if (nt > 0 && nt <= BIN_COOP)
+            for (int ty = t.ty0; ty < t.ty1; ++ty)
+                for (int tx = t.tx0; tx < t.tx1; ++tx) visit(i, tx, ty);
+        unsigned long long big = __ballot(nt > BIN_COOP);
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            big &= big - 1;
+            const int bx0 = __shfl(t.tx0, src), by0 = __shfl(t.ty0, src), bnx = __shfl(ntx, src), bnt = __shfl(nt, src);
+            for (int k = lane; k < bnt; k += 64) visit(base + src, bx0 + k % bnx, by0 + k / bnx);
+        }
+    }
+}
+
+// exclusive scan of the tile counts (single workgroup); zeroes the counts for the next draw and
+// the fill cursors; publishes bin_total and the bin-capacity overflow flag.
+__global__ __launch_bounds__(1024) void k_tile_scan(RasterArgs a, uint32_t ntiles)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < ntiles; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < ntiles ? a.tile_counts[i] : 0u;
+        uint32_t inc = wave_incl_scan(v);
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { uint32_t x = s_w[k]; if (k < w) wbase += x; tot += x; }
+        uint32_t carry = s_carry;
+        if (i < ntiles) { a.tile_offsets[i] = carry + wbase + inc - v; a.tile_counts[i] = 0; a.tile_cursor[i] = 0; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        uint32_t total = s_carry;
+        a.tile_offsets[ntiles] = total;
+        a.cnt->bin_total = total;
+        a.cnt->bin_entries_frame += total;
+        if (total > a.bin_cap) a.cnt->overflow |= 2u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3 tile raster + resolve.  One workgroup (4 waves) per 32x32 tile; per-pixel 64-bit keys
+// (zkey(rhw) << 32 | triangle+1) live in LDS.  One triangle per wavefront: the wave loads the
+// triangle's 64-byte record with scalar loads, its 64 lanes sweep the bbox-in-tile pixels
+// (packed row-major, 64 per step), evaluate the integer edge functions (renderer.rs:329-341),
+// the float barycentrics and rhw (:343-360), and resolve the z-test (:363-366) with an LDS
+// atomic max: argmax over (rhw, emission index) is exactly the sequential rule "later fragment
+// wins ties" (SURVEY A.6).  After the last triangle each pixel's winner is re-evaluated, shaded
+// (:368-381) and stored with row-contiguous stores.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    // blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of tiles so
+    // neighbouring tiles (which share triangle records) share an L2.  Bijective for any nwg.
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+}
+
+template <int K, int PS>
+__global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
+{
+    __shared__ unsigned long long s_key[TILE_PX];
+    const int tid = threadIdx.x;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = bid % a.tiles_x;
+    const int ty = a.rank + (bid / a.tiles_x) * a.world;
+    const int tile = ty * a.tiles_x + tx;
+    const int lx0 = tx * TILE, ly0 = ty * TILE;                 // window-local tile origin
+    const int tw = min(TILE, a.win_w - lx0), th = min(TILE, a.win_h - ly0);
+    const uint32_t beg = a.tile_offsets[tile], end = min(a.tile_offsets[tile + 1], a.bin_cap);
+    if (beg >= end) return; // nothing binned here: colour, depth and ids stay as they are
+
+    for (int i = tid; i < TILE_PX; i += 256) {
+        const int x = i & (TILE - 1), y = i >> 5;
+        float d = 0.0f;
+        if (x < tw && y < th) d = a.depth[(size_t)(ly0 + y) * a.dstride + (lx0 + x)];
+        s_key[i] = (unsigned long long)zkey(d) << 32;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ax0 = a.x0 + lx0, ay0 = a.y0 + ly0;               // absolute pixel of the tile origin
+    uint32_t n_cov = 0, n_nan = 0;
+    for (uint32_t e = beg + wave; e < end; e += 4) {
+        const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e]);
+        const RasterRec *__restrict__ r = a.recs + t;
+        const int p0x = r->p[0], p0y = r->p[1], p1x = r->p[2], p1y = r->p[3], p2x = r->p[4], p2y = r->p[5];
+        // clamped bbox (renderer.rs:285-298; clamp is monotone so it commutes with min/max)
+        int bx0 = clampi(min(p0x, min(p1x, p2x)), a.x0, a.x1), bx1 = clampi(max(p0x, max(p1x, p2x)), a.x0, a.x1);
+        int by0 = clampi(min(p0y, min(p1y, p2y)), a.y0, a.y1), by1 = clampi(max(p0y, max(p1y, p2y)), a.y0, a.y1);
+        bx0 = max(bx0, ax0); bx1 = min(bx1, ax0 + tw);          // ... intersected with this tile
+        by0 = max(by0, ay0); by1 = min(by1, ay0 + th);
+        const int bw = bx1 - bx0, bh = by1 - by0;
+        if (bw <= 0 || bh <= 0) continue;
+        const int npx = bw * bh;
+        // edge functions E = A*(cx - px) + B*(cy - py) in wrapping i32 (renderer.rs:329-331)
+        const uint32_t A01 = 0u - (uint32_t)(p1y - p0y), B01 = (uint32_t)(p1x - p0x);
+        const uint32_t A12 = 0u - (uint32_t)(p2y - p1y), B12 = (uint32_t)(p2x - p1x);
+        const uint32_t A20 = 0u - (uint32_t)(p0y - p2y), B20 = (uint32_t)(p0x - p2x);
+        const uint32_t E01o = A01 * (uint32_t)(bx0 - p0x) + B01 * (uint32_t)(by0 - p0y);
+        const uint32_t E12o = A12 * (uint32_t)(bx0 - p1x) + B12 * (uint32_t)(by0 - p1y);
+        const uint32_t E20o = A20 * (uint32_t)(bx0 - p2x) + B20 * (uint32_t)(by0 - p2y);
+        const uint32_t fl = r->flags;
+        // reject E < bias  <=>  accept E > bias-1   (bias 0 for top-left edges, else 1; :333-341)
+        const int thr01 = (fl & 2u) ? 0 : -1, thr12 = (fl & 4u) ? 0 : -1, thr20 = (fl & 8u) ? 0 : -1;
+        const float s0x = r->s[0], s0y = r->s[1], s1x = r->s[2], s1y = r->s[3], s2x = r->s[4], s2y = r->s[5];
+        const float r0 = r->rhw[0], r1 = r->rhw[1], r2 = r->rhw[2];
+        const float inv_bw = 1.0f / (float)bw;
+        const unsigned long long idlow = (unsigned long long)(t + 1u);
+        for (int p = lane; p < npx; p += 64) {
+            const int dy = (int)(((float)p + 0.5f) * inv_bw);   // exact for p < 1024, bw <= 32
+            const int dx = p - dy * bw;
+            const int E01 = (int)(E01o + A01 * (uint32_t)dx + B01 * (uint32_t)dy);
+            const int E12 = (int)(E12o + A12 * (uint32_t)dx + B12 * (uint32_t)dy);
+            const int E20 = (int)(E20o + A20 * (uint32_t)dx + B20 * (uint32_t)dy);
+            const bool covered = (E01 > thr01) & (E12 > thr12) & (E20 > thr20);
+            n_cov += (uint32_t)__popcll(__ballot(covered));
+            if (covered) {
+                const int cx = bx0 + dx, cy = by0 + dy;
+                Frag f = frag_eval(s0x, s0y, s1x, s1y, s2x, s2y, r0, r1, r2, cx, cy);
+                if (f.valid) {
+                    if (f.rhw != f.rhw) ++n_nan;
+                    const unsigned long long key = ((unsigned long long)zkey(f.rhw) << 32) | idlow;
+                    atomicMax(&s_key[(cy - ay0) * TILE + (cx - ax0)], key);
+                }
+            }
+        }
+    }
+    if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
+    if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
+    __syncthreads();
+
+    // resolve: the owner of each pixel is re-evaluated with the same arithmetic and written out
+    const uint32_t tri_base = a.cnt->tri_base;
+    for (int i = tid; i < TILE_PX; i += 256) {
+        const int x = i & (TILE - 1), y = i >> 5;
+        if (x >= tw || y >= th) continue;
+        const uint32_t id = (uint32_t)s_key[i];
+        if (id == 0u) continue; // existing depth won (or nothing covered this pixel)
+        const uint32_t t = id - 1u;
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + t);
+        const uint4 q1 = rp[1], q2 = rp[2], q3 = rp[3];
+        const int cx = ax0 + x, cy = ay0 + y;
+        const float r0 = u2f(q3.x), r1 = u2f(q3.y), r2 = u2f(q3.z);
+        Frag f = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), r0, r1, r2, cx, cy);
+        const size_t di = (size_t)(ly0 + y) * a.dstride + (lx0 + x);
+        a.depth[di] = f.rhw;                                                    // :366
+        a.tri_id[di] = tri_base + t;
+        if constexpr (PS != FRR_PS_DEPTH) {
+            const float w = 1.0f / (f.rhw != 0.0f ? f.rhw : 1.0f);              // :368
+            const float c0 = r0 * f.a * w, c1 = r1 * f.b * w, c2 = r2 * f.c * w; // :370-372
+            float in[K > 0 ? K : 1];
+            if constexpr (K > 0) {
+                const float *v = a.vary + (size_t)t * (3 * K);
+#pragma unroll
+                for (int k = 0; k < K; ++k) in[k] = v[k] * c0 + v[K + k] * c1 + v[2 * K + k] * c2; // :374-378
+            }
+            float col[4];
+            run_ps<PS>(u, in, col);                                             // :380
+            const uint32_t q = quantize_u8(col[0]) | (quantize_u8(col[1]) << 8) | (quantize_u8(col[2]) << 16) |
+                               (quantize_u8(col[3]) << 24);                     // :7-14
+            reinterpret_cast<uint32_t *>(a.color)[(size_t)(ly0 + y) * a.cstride + (lx0 + x)] = q; // :381,:496-503
+        }
+    }
+}
+
+// ---- debug --------------------------------------------------------------------------------
+__global__ void k_debug_atan2f(const float *y, const float *x, float *out, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fd_atan2f(y[i], x[i]);
+}
+
+} // namespace frr

@@ -1,0 +1,182 @@
+/*
+ * frr.h -- C ABI of libfrr_hip.so: the MI355X (gfx950) rasterization path behind
+ * vmskisme/f_renderer's Renderer / FrameBuffer surface.
+ *
+ * The reference API is per-triangle and closure-based (Rust generics):
+ *   Renderer::geometry_processing   /root/reference/f_renderer/src/renderer.rs:96-112
+ *   Renderer::rasterization         /root/reference/f_renderer/src/renderer.rs:269-284
+ *   FrameBuffer::{new,fill,clear,get_data,get_size,set_pixel,get_pixel,sample_2d}
+ *                                   /root/reference/f_renderer/src/renderer.rs:418-538
+ * driven by the two-pass draw loop   /root/reference/examples/src/bin/phong.rs:314-387.
+ * Closures and generic varyings cannot cross an FFI to a GPU, so this ABI is batched at the
+ * granularity of that draw loop and shaders are table-selected; varyings are a flat float[K]
+ * (the trait bounds Add+Sub+Mul<f32>+Copy+Default, renderer.rs:97-102, say "K-dim real vector").
+ * Plain pointers and sizes only; no torch / C++ types.  All functions return FRR_OK (0) or a
+ * negative frr_status; nothing unwinds across this boundary.  A frr_ctx is driven by one host
+ * thread (the reference is single-threaded, vulkan_base.rs:698-723).
+ *
+ * There is NO CPU fallback behind these symbols: every entry point that computes needs a gfx950
+ * device and fails with FRR_ERR_HIP otherwise.
+ */
+#ifndef FRR_H
+#define FRR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRR_ABI_VERSION 1
+#define FRR_MAX_VARYINGS 16
+#define FRR_MAX_TEXTURES 4
+#define FRR_MAX_OUT_TRIS 19 /* 3 + 18 clip vertices -> 19 fan triangles (renderer.rs:150-171,245-264) */
+
+typedef struct frr_ctx frr_ctx;
+
+typedef enum frr_status {
+    FRR_OK = 0,
+    FRR_ERR_INVALID = -1,     /* bad argument (the reference would panic: clamp min>max, OOB index) */
+    FRR_ERR_HIP = -2,         /* HIP runtime error / no gfx950 device; see frr_last_error */
+    FRR_ERR_NOMEM = -3,
+    FRR_ERR_UNSUPPORTED = -4,
+    FRR_ERR_CAPACITY = -5     /* a device work list overflowed during the frame; the ctx has grown
+                                 it, re-issue the frame (reported by frr_sync/frr_readback/frr_stats) */
+} frr_status;
+
+/* Vertex-shader table.  Replaces the `vertex_shader: &F` closure argument (renderer.rs:105,110). */
+typedef enum frr_vs {
+    FRR_VS_CLIP = 0,       /* VSInput = clip xyzw (4 f32);               K = 0 */
+    FRR_VS_CLIP_COLOR = 1, /* VSInput = clip xyzw + rgb (7 f32);         K = 3 */
+    FRR_VS_PHONG = 2,      /* VSInput = pos3,uv2,normal3 (phong.rs:49-54); body phong.rs:114-126; K = 8 */
+    FRR_VS_GOURAUD = 3     /* same input; per-vertex Lambert colour;     K = 3 */
+} frr_vs;
+
+/* Pixel-shader table.  Replaces the `pixel_shader: &F` closure argument (renderer.rs:273,283). */
+typedef enum frr_ps {
+    FRR_PS_DEPTH = 0, /* depth (+triangle id) only, colour untouched */
+    FRR_PS_FLAT = 1,  /* uniforms.flat_color */
+    FRR_PS_COLOR = 2, /* (ctx[0],ctx[1],ctx[2],1) */
+    FRR_PS_PHONG = 3, /* phong.rs:133-154 (reflect-vector Phong x bilinear texture) */
+    FRR_PS_BLINN = 4  /* half-vector variant of the same (not in the reference) */
+} frr_ps;
+
+/* VSUniform (phong.rs:26-31) + PSUniform (phong.rs:41-47) + light consts (phong.rs:128-132).
+ * Matrices column-major like glam::Mat4::from_cols_array (matrix_util.rs:5-7). */
+typedef struct frr_uniforms {
+    float model[16], view[16], proj[16];
+    float view_pos[3];
+    float light_pos[3];
+    float light_color[3];
+    float ambient_strength;
+    float specular_strength;
+    float flat_color[4];
+    int32_t texture_slot; /* PSUniform.place (phong.rs:34-38,147-151) */
+} frr_uniforms;
+
+/* One post-setup vertex as the parity tests read it back: the caller-visible content of
+ * Vertex<T> (renderer.rs:387-394) minus the NDC `pos`, in EMISSION order (before the
+ * orientation swap of renderer.rs:309-312). */
+typedef struct frr_setup_vertex {
+    float spf[2];
+    int32_t spi[2];
+    float rhw;
+    float ctx[FRR_MAX_VARYINGS];
+} frr_setup_vertex;
+
+typedef struct frr_stats {
+    uint64_t tris_in;      /* input triangles submitted since the last frr_clear */
+    uint64_t tris_setup;   /* triangles after clip + fan */
+    uint64_t bin_entries;  /* (triangle, tile) pairs */
+    uint64_t frag_covered; /* pass the edge tests renderer.rs:333-341 (only if counting enabled) */
+    uint64_t frag_nan;     /* NaN rhw fragments (unsupported: sticky in the reference) */
+    uint32_t draws;
+    uint32_t overflow;     /* non-zero => this frame is invalid, see FRR_ERR_CAPACITY */
+} frr_stats;
+
+/* ---- context ------------------------------------------------------------------------------ */
+
+/* Creates a context on HIP device `device` with a width x height FrameBuffer (renderer.rs:419-425),
+ * an f32 depth buffer (phong.rs:208) and a u32 triangle-id buffer.  `stream` is a hipStream_t the
+ * caller owns (e.g. torch's current stream), or NULL for a private stream. */
+int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ctx **out);
+void frr_destroy(frr_ctx *ctx);
+const char *frr_last_error(const frr_ctx *ctx);
+int frr_abi_version(void);
+
+/* Screen-tile partition for multi-GPU runs: this ctx rasterizes only tile rows ty with
+ * ty % world == rank (geometry is replicated).  Default (0,1) = everything. */
+int frr_set_partition(frr_ctx *ctx, int rank, int world);
+/* Counting covered fragments costs one atomic per wave iteration; off by default. */
+int frr_set_count_fragments(frr_ctx *ctx, int enable);
+
+/* Use caller-owned DEVICE buffers (e.g. torch tensors) as the frame targets instead of the
+ * internally allocated ones; any may be NULL to keep the internal one. */
+int frr_bind_targets(frr_ctx *ctx, void *color_rgba8, void *depth_f32, void *tri_id_u32);
+int frr_target_ptrs(frr_ctx *ctx, void **color_rgba8, void **depth_f32, void **tri_id_u32);
+
+/* ---- scene ------------------------------------------------------------------------------- */
+
+/* Vec<[VSInput;3]> (phong.rs:187-205): ntris x 3 x floats_per_vertex(vs) f32, host memory. */
+int frr_mesh_upload(frr_ctx *ctx, const float *vs_inputs, uint64_t ntris, int vs_id, int *mesh_out);
+/* Same, data already in device memory (borrowed until frr_mesh_free). */
+int frr_mesh_bind_device(frr_ctx *ctx, const void *dev_vs_inputs, uint64_t ntris, int vs_id, int *mesh_out);
+int frr_mesh_free(frr_ctx *ctx, int mesh);
+/* FrameBuffer used as texture (PSUniform.sample_2d_*, phong.rs:43-45): RGBA8 row-major.
+ * height >= width is required: sample_2d clamps y with width (renderer.rs:523,525), so a
+ * shorter texture is an out-of-bounds panic in the reference. */
+int frr_texture_upload(frr_ctx *ctx, int slot, const uint8_t *rgba, uint32_t width, uint32_t height);
+int frr_set_uniforms(frr_ctx *ctx, const frr_uniforms *u);
+int frr_vs_input_floats(int vs_id);
+int frr_vs_num_varyings(int vs_id);
+
+/* ---- frame ------------------------------------------------------------------------------- */
+
+/* frame_buffer.fill(rgba) + depth_buffer.fill(depth)  (phong.rs:316-317, renderer.rs:485-494) */
+int frr_clear(frr_ctx *ctx, const uint8_t rgba[4], float depth);
+
+/* Loop A (phong.rs:321-331): Renderer::geometry_processing over every input triangle of `mesh`,
+ * results concatenated in submission order on the device.  *ntris_setup (optional) forces a
+ * stream sync to return the count. */
+int frr_geometry(frr_ctx *ctx, int mesh, uint64_t *ntris_setup);
+/* Loop B (phong.rs:361-381): Renderer::rasterization of the triangles of the last frr_geometry
+ * with width_range=(x0,x1), height_range=(y0,y1) (renderer.rs:270-271).  As in the reference the
+ * window is addressed locally: pixel (cx,cy) lands at colour (cx-x0, cy-y0) with row stride
+ * `width` and at depth index (cy-y0)*x1 + (cx-x0) (renderer.rs:323,326,362,381). */
+int frr_raster(frr_ctx *ctx, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1);
+/* frr_geometry + frr_raster */
+int frr_draw(frr_ctx *ctx, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1);
+
+int frr_sync(frr_ctx *ctx);
+/* FrameBuffer::get_data (renderer.rs:473-475) + depth + triangle ids -> host; NULLs skipped.
+ * tri_id holds, per depth-buffer index, the global emission index (over the draws since the last
+ * frr_clear) of the triangle owning the pixel, 0xFFFFFFFF where nothing was drawn. */
+int frr_readback(frr_ctx *ctx, uint8_t *rgba, float *depth, uint32_t *tri_id);
+/* Vec<[Vertex;3]> of the last frr_geometry, [n][3] frr_setup_vertex, emission order */
+int frr_readback_setup(frr_ctx *ctx, frr_setup_vertex *out, uint64_t cap_tris, uint64_t *ntris);
+int frr_get_stats(frr_ctx *ctx, frr_stats *out);
+
+/* ---- timing on the ctx stream (HIP events) -------------------------------------------------- */
+/* slot in [0,16): record an event now; elapsed in ms between two recorded slots (syncs on `b`). */
+int frr_event_record(frr_ctx *ctx, int slot);
+int frr_event_elapsed_ms(frr_ctx *ctx, int a, int b, float *ms);
+/* per-kernel accumulated device time (ms) and launch count since frr_profile_reset; enabling
+ * profiling brackets every launch with events (adds host overhead; not for throughput runs). */
+int frr_profile_enable(frr_ctx *ctx, int enable);
+int frr_profile_reset(frr_ctx *ctx);
+int frr_profile_get(frr_ctx *ctx, const char *kernel, float *total_ms, uint32_t *launches);
+
+/* ---- host helpers mirroring matrix_util.rs:3-35 (pure host arithmetic, no device) --------- */
+void frr_set_identity(float m[16]);
+void frr_set_look_at(const float eye[3], const float at[3], const float up[3], float m[16]);
+void frr_set_perspective(float fovy, float aspect, float zn, float zf, float m[16]);
+
+/* ---- debug / parity hooks ----------------------------------------------------------------- */
+/* device evaluation of the library's atan2f (bit-exact fdlibm port) on n (y,x) pairs */
+int frr_debug_atan2f(frr_ctx *ctx, const float *y, const float *x, float *out, uint64_t n);
+/* the same source compiled for the host, to pin the port against glibc without a GPU */
+float frr_host_atan2f(float y, float x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
