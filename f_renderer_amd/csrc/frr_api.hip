@@ -60,7 +60,7 @@ struct frr_ctx {
     int rank = 0, world = 1;
     hipEvent_t ev[16] = {};
     bool ev_set[16] = {};
-    bool profiling = false;
+    uint32_t prof_mask = 0;   // bit per KernelId
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
     double prof_ms[KID_COUNT] = {};
@@ -105,11 +105,11 @@ struct ProfScope {
     frr_ctx *c; int kid; hipEvent_t a = nullptr;
     ProfScope(frr_ctx *c_, int kid_) : c(c_), kid(kid_)
     {
-        if (c->profiling) { a = get_event(c); (void)hipEventRecord(a, c->stream); }
+        if (c->prof_mask & (1u << kid)) { a = get_event(c); (void)hipEventRecord(a, c->stream); }
     }
     ~ProfScope()
     {
-        if (c->profiling) { hipEvent_t b = get_event(c); (void)hipEventRecord(b, c->stream); c->prof_pending.push_back({kid, a, b}); }
+        if (a) { hipEvent_t b = get_event(c); (void)hipEventRecord(b, c->stream); c->prof_pending.push_back({kid, a, b}); }
     }
 };
 void prof_collect(frr_ctx *c)
@@ -563,7 +563,7 @@ int frr_profile_enable(frr_ctx *c, int enable)
 {
     if (!c) return FRR_ERR_INVALID;
     prof_collect(c);
-    c->profiling = enable != 0;
+    c->prof_mask = enable < 0 ? 0xFFFFFFFFu : (uint32_t)enable;
     return FRR_OK;
 }
 int frr_profile_reset(frr_ctx *c)

@@ -267,8 +267,13 @@ class Renderer:
         self._check(self._lib.frr_event_elapsed_ms(self._ctx, a, b, C.byref(ms)))
         return float(ms.value)
 
-    def profile_enable(self, on=True):
-        self._check(self._lib.frr_profile_enable(self._ctx, 1 if on else 0))
+    KERNELS = ("k_clear", "k_geom_count", "k_scan_blocks", "k_geom_emit", "k_geom_emit_clip", "k_bin_count",
+               "k_tile_scan", "k_bin_fill", "k_raster")
+
+    def profile_enable(self, on=True, kernels=None):
+        """Bracket launches with HIP events: all kernels (on=True), none (False) or the named ones."""
+        mask = (-1 if on else 0) if kernels is None else sum(1 << self.KERNELS.index(k) for k in kernels)
+        self._check(self._lib.frr_profile_enable(self._ctx, mask))
 
     def profile_reset(self):
         self._check(self._lib.frr_profile_reset(self._ctx))

@@ -159,9 +159,11 @@ int frr_get_stats(frr_ctx *ctx, frr_stats *out);
 /* slot in [0,16): record an event now; elapsed in ms between two recorded slots (syncs on `b`). */
 int frr_event_record(frr_ctx *ctx, int slot);
 int frr_event_elapsed_ms(frr_ctx *ctx, int a, int b, float *ms);
-/* per-kernel accumulated device time (ms) and launch count since frr_profile_reset; enabling
- * profiling brackets every launch with events (adds host overhead; not for throughput runs). */
-int frr_profile_enable(frr_ctx *ctx, int enable);
+/* per-kernel accumulated device time (ms) and launch count since frr_profile_reset.  `mask`:
+ * 0 = off, -1 = every kernel, else OR of (1 << index) with index in the order k_clear,
+ * k_geom_count, k_scan_blocks, k_geom_emit, k_geom_emit_clip, k_bin_count, k_tile_scan,
+ * k_bin_fill, k_raster.  A profiled launch is bracketed by two HIP events on the ctx stream. */
+int frr_profile_enable(frr_ctx *ctx, int mask);
 int frr_profile_reset(frr_ctx *ctx);
 int frr_profile_get(frr_ctx *ctx, const char *kernel, float *total_ms, uint32_t *launches);
 

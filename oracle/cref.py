@@ -187,7 +187,7 @@ def geometry_batch(width, height, vs_inputs, vs_id, uniforms, cap=None):
     vin = np.ascontiguousarray(vs_inputs, np.float32)
     nf = vs_input_floats(vs_id)
     ntris = vin.size // (3 * nf)
-    cap = cap or (ntris * O_MAX_OUT_TRIS if ntris < 4096 else ntris * 2 + 4096)
+    cap = cap or ntris * O_MAX_OUT_TRIS
     out = np.zeros((cap, 3), VERTEX_DTYPE)
     n = lib().o_geometry_batch(width, height, _f32p(vin.reshape(-1)), ntris, vs_id, C.byref(uniforms),
                                out.ctypes.data, cap)
@@ -229,7 +229,7 @@ class Frame:
         x0, x1, y0, y1 = window if window is not None else (0, self.width, 0, self.height)
         setup, cap, ptr = None, 0, None
         if keep_setup:
-            cap = ntris * O_MAX_OUT_TRIS if ntris < 4096 else ntris * 2 + 4096
+            cap = ntris * O_MAX_OUT_TRIS
             setup = np.zeros((cap, 3), VERTEX_DTYPE)
             ptr = setup.ctypes.data
         before = int(self.counters.tris_setup)

@@ -77,7 +77,8 @@ def test_rgb_triangle_interpolated(oracle):
 @pytest.mark.parametrize("W,H,n,spread,wj,seed", [
     (256, 256, 5000, 0.95, 0.1, 1),
     (333, 211, 20000, 1.15, 0.1, 2),      # ragged size, many clipped triangles
-    (640, 360, 20000, 1.3, 1.5, 3),       # negative / tiny w: the quirky clipper's kept outside vertices
+    (320, 180, 1500, 1.3, 1.5, 3),        # negative / tiny w: the quirky clipper's kept outside vertices,
+                                          # screen-filling fans, saturated spi and wrapping edge functions
     (64, 64, 3000, 2.0, 0.5, 4),          # most triangles partly or wholly off screen
 ])
 def test_random_triangles_depth_and_setup(oracle, W, H, n, spread, wj, seed):
