@@ -14,10 +14,10 @@ using namespace frr;
 namespace {
 
 enum KernelId { KID_CLEAR, KID_GEOM_COUNT, KID_SCAN_BLOCKS, KID_GEOM_EMIT, KID_GEOM_EMIT_CLIP, KID_BIN_COUNT,
-                KID_TILE_SCAN, KID_BIN_FILL, KID_RASTER, KID_COUNT };
+                KID_TILE_SCAN, KID_BIN_FILL, KID_RASTER, KID_BIN_COLSCAN, KID_COUNT };
 const char *const kKernelNames[KID_COUNT] = {"k_clear", "k_geom_count", "k_scan_blocks", "k_geom_emit",
                                              "k_geom_emit_clip", "k_bin_count", "k_tile_scan", "k_bin_fill",
-                                             "k_raster"};
+                                             "k_raster", "k_bin_colscan"};
 
 struct Mesh {
     const float *dev = nullptr;
@@ -51,6 +51,8 @@ struct frr_ctx {
     uint32_t *tile_counts = nullptr, *tile_offsets = nullptr, *tile_cursor = nullptr;
     uint32_t max_tiles = 0;
     uint32_t *bins = nullptr; size_t bin_cap = 0;
+    uint32_t *bin_matrix = nullptr; size_t bin_matrix_cap = 0; // [G][ntiles] per-chunk tile histograms
+    bool lds_attr_set = false;
     std::vector<Mesh> meshes;
     Texture tex[FRR_MAX_TEXTURES];
     frr_uniforms uni;
@@ -266,7 +268,7 @@ void frr_destroy(frr_ctx *c)
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
     void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->clip_list, c->recs, c->vary,
-                    c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins};
+                    c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bin_matrix};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -456,10 +458,27 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     }
     a.bins = c->bins; a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xFFFFFFFFu);
     a.color = c->color; a.depth = c->depth; a.tri_id = c->tri_id; a.cnt = c->cnt;
-    const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(c->geom_ntris * FRR_MAX_OUT_TRIS, c->setup_cap) + 255) / 256, 2048);
-    { ProfScope p(c, KID_BIN_COUNT); hipLaunchKernelGGL(k_bin<false>, dim3(bin_grid), dim3(256), 0, c->stream, a); }
-    { ProfScope p(c, KID_TILE_SCAN); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, a, ntiles); }
-    { ProfScope p(c, KID_BIN_FILL); hipLaunchKernelGGL(k_bin<true>, dim3(bin_grid), dim3(256), 0, c->stream, a); }
+    if (ntiles <= BIN_LDS_MAX_TILES) {
+        // LDS multi-split (no global atomics): G chunk workgroups, ~3K triangles each
+        const uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + 3071) / 3072, 1), BIN_MAX_G);
+        if ((rc = ensure(c, c->bin_matrix, c->bin_matrix_cap, (size_t)BIN_MAX_G * c->max_tiles)) != FRR_OK) return rc;
+        const size_t lds = (size_t)ntiles * sizeof(uint32_t);
+        if (!c->lds_attr_set) {
+            HIP_TRY(c, hipFuncSetAttribute((const void *)k_bin_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_LDS_MAX_TILES * 4));
+            HIP_TRY(c, hipFuncSetAttribute((const void *)k_bin_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_LDS_MAX_TILES * 4));
+            c->lds_attr_set = true;
+        }
+        { ProfScope p(c, KID_BIN_COUNT); hipLaunchKernelGGL(k_bin_lds<false>, dim3(G), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix); }
+        { ProfScope p(c, KID_BIN_COLSCAN); hipLaunchKernelGGL(k_bin_colscan, dim3((ntiles + 31) / 32), dim3(256), 0, c->stream, c->bin_matrix, G, ntiles, c->tile_counts); }
+        { ProfScope p(c, KID_TILE_SCAN); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, a, ntiles); }
+        { ProfScope p(c, KID_BIN_FILL); hipLaunchKernelGGL(k_bin_lds<true>, dim3(G), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix); }
+    } else {
+        // fallback for frames with more tiles than fit LDS counters: global atomics
+        const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(c->geom_ntris * FRR_MAX_OUT_TRIS, c->setup_cap) + 255) / 256, 2048);
+        { ProfScope p(c, KID_BIN_COUNT); hipLaunchKernelGGL(k_bin<false>, dim3(bin_grid), dim3(256), 0, c->stream, a); }
+        { ProfScope p(c, KID_TILE_SCAN); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, a, ntiles); }
+        { ProfScope p(c, KID_BIN_FILL); hipLaunchKernelGGL(k_bin<true>, dim3(bin_grid), dim3(256), 0, c->stream, a); }
+    }
     const int owned_rows = a.tiles_y > a.rank ? (a.tiles_y - a.rank + a.world - 1) / a.world : 0;
     const uint32_t grid = (uint32_t)a.tiles_x * owned_rows;
     if (grid) {

@@ -183,20 +183,20 @@ __device__ __forceinline__ uint32_t classify(const float pos[3][4], bool &clippe
     if ((in0 & in1 & in2) == 63u) return 1;
     clipped = true;
     uint32_t n = 3;
-    const uint32_t inb[3] = {in0, in1, in2};
+    // pairs (0,1),(0,2),(1,2) x planes in list order (:152-169); spelled out so that every index is
+    // a compile-time constant (runtime-indexed arrays would go to scratch)
+    auto pair = [&](const float *a, const float *b, uint32_t diff) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = i + 1; j < 3; ++j) {
-            uint32_t diff = inb[i] ^ inb[j];
-#pragma unroll
-            for (int p = 0; p < 6; ++p)
-                if (diff & (1u << p)) {
-                    float t = intersect_ratio(p, pos[i], pos[j]);
-                    float w = pos[i][3] + t * (pos[j][3] - pos[i][3]);  // :89, w lane
-                    if (fabsf(w) > CLIP_EPSILON) ++n;                   // :164
-                }
-        }
+        for (int p = 0; p < 6; ++p)
+            if (diff & (1u << p)) {
+                float t = intersect_ratio(p, a, b);
+                float w = a[3] + t * (b[3] - a[3]);                 // :89, w lane
+                if (fabsf(w) > CLIP_EPSILON) ++n;                   // :164
+            }
+    };
+    pair(pos[0], pos[1], in0 ^ in1);
+    pair(pos[0], pos[2], in0 ^ in2);
+    pair(pos[1], pos[2], in1 ^ in2);
     return n - 2;
 }
 

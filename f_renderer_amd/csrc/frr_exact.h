@@ -57,9 +57,8 @@ FRR_HD int32_t total_order_key(float f)
 // for all non-NaN a,b, with -0.0 and +0.0 mapped to the same key (they compare equal).
 FRR_HD uint32_t zkey(float f)
 {
-    uint32_t u = f2u(f);
-    if ((u << 1) == 0u) return 0x80000000u; // +-0
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    uint32_t u = f2u(f + 0.0f); // -0.0 + 0.0 == +0.0 (round-to-nearest); every other value unchanged
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
 }
 FRR_HD float zkey_decode(uint32_t k)
 {

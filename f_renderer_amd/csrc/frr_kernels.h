@@ -4,6 +4,7 @@
 // raster+resolve per 32x32 screen tile }.  See DESIGN.md for the roofline of each kernel.
 #pragma once
 #include "frr_device.h"
+#include <type_traits>
 
 namespace frr {
 
@@ -344,6 +345,95 @@ __global__ __launch_bounds__(1024) void k_tile_scan(RasterArgs a, uint32_t ntile
 }
 
 // ---------------------------------------------------------------------------------------------
+// K2' binning without global atomics (default path): an LDS multi-split.
+//   k_bin_lds<false>: workgroup g of G histograms its contiguous chunk of setup triangles over
+//                     the tiles in LDS (ds_add) and stores the row M[g][*] (coalesced);
+//   k_bin_colscan   : per tile, exclusive prefix over g of M[*][tile] (in LDS, 32 tiles per
+//                     workgroup) and the tile total -> tile_counts;
+//   k_tile_scan     : exclusive scan of the totals -> tile_offsets (CSR);
+//   k_bin_lds<true> : workgroup g loads cursor[tile] = tile_offsets[tile] + M[g][tile] into LDS and
+//                     scatters its triangles' indices with returning LDS atomics + plain stores.
+// Scattered memory-side atomics (k_bin above: ~7 G/s on MI355X) are avoided entirely; the old path
+// remains as the fallback when the tile count does not fit LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int BIN_WG = 512;
+constexpr int BIN_MAX_G = 256;
+constexpr uint32_t BIN_LDS_MAX_TILES = 36864; // 144 KiB of u32 counters
+
+template <bool SCATTER>
+__global__ __launch_bounds__(BIN_WG) void k_bin_lds(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ M)
+{
+    extern __shared__ uint32_t s_hist[]; // [ntiles]
+    const uint32_t g = blockIdx.x, G = gridDim.x;
+    uint32_t *__restrict__ row = M + (size_t)g * ntiles;
+    for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) s_hist[t] = SCATTER ? a.tile_offsets[t] + row[t] : 0u;
+    __syncthreads();
+    const uint32_t n = a.cnt->n_setup;
+    uint32_t chunk = (n + G - 1) / G;
+    chunk = (chunk + 63u) & ~63u;
+    const uint32_t lo = min(n, g * chunk), hi = min(n, lo + chunk);
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (uint32_t base = lo + wave * 64u; base < hi; base += (BIN_WG / 64) * 64u) {
+        const uint32_t i = base + lane;
+        TileRange t = {0, 0, 0, 0};
+        if (i < hi) t = tri_tiles(a, a.recs + i);
+        const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
+        const int nt = ntx * nty;
+        auto visit = [&](uint32_t tri, int tx, int ty) {
+            if (ty % a.world != a.rank) return;
+            const int tile = ty * a.tiles_x + tx;
+            if constexpr (SCATTER) {
+                const uint32_t pos = atomicAdd(&s_hist[tile], 1u);
+                if (pos < a.bin_cap) a.bins[pos] = tri;
+            } else {
+                atomicAdd(&s_hist[tile], 1u);
+            }
+        };
+        if (nt > 0 && nt <= BIN_COOP)
+            for (int ty = t.ty0; ty < t.ty1; ++ty)
+                for (int tx = t.tx0; tx < t.tx1; ++tx) visit(i, tx, ty);
+        unsigned long long big = __ballot(nt > BIN_COOP);
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            big &= big - 1;
+            const int bx0 = __shfl(t.tx0, src), by0 = __shfl(t.ty0, src), bnx = __shfl(ntx, src), bnt = __shfl(nt, src);
+            for (int k = lane; k < bnt; k += 64) visit(base + src, bx0 + k % bnx, by0 + k / bnx);
+        }
+    }
+    if constexpr (!SCATTER) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) row[t] = s_hist[t];
+    }
+}
+
+// M[g][tile] -> exclusive prefix over g (in place); tile_counts[tile] = column total.
+// One workgroup per 32 tiles: 256 threads = 32 tile columns x 8 segments of g.
+__global__ __launch_bounds__(256) void k_bin_colscan(uint32_t *__restrict__ M, uint32_t G, uint32_t ntiles,
+                                                     uint32_t *__restrict__ tile_counts)
+{
+    __shared__ uint32_t s[BIN_MAX_G][32];
+    __shared__ uint32_t s_part[8][32];
+    const uint32_t tl = threadIdx.x & 31, gs = threadIdx.x >> 5;
+    const uint32_t t = blockIdx.x * 32 + tl;
+    const bool ok = t < ntiles;
+    for (uint32_t g = gs; g < G; g += 8) s[g][tl] = ok ? M[(size_t)g * ntiles + t] : 0u;
+    __syncthreads();
+    const uint32_t seg = (G + 7) / 8, g0 = min(G, gs * seg), g1 = min(G, g0 + seg);
+    uint32_t sum = 0;
+    for (uint32_t g = g0; g < g1; ++g) sum += s[g][tl];
+    s_part[gs][tl] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) { const uint32_t x = s_part[k][tl]; if (k < gs) run += x; total += x; }
+    for (uint32_t g = g0; g < g1; ++g) { const uint32_t x = s[g][tl]; s[g][tl] = run; run += x; }
+    if (gs == 0 && ok) tile_counts[t] = total;
+    __syncthreads();
+    for (uint32_t g = gs; g < G; g += 8) if (ok) M[(size_t)g * ntiles + t] = s[g][tl];
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3 tile raster + resolve.  One workgroup (4 waves) per 32x32 tile; per-pixel 64-bit keys
 // (zkey(rhw) << 32 | triangle+1) live in LDS.  One triangle per wavefront: the wave loads the
 // triangle's 64-byte record with scalar loads, its 64 lanes sweep the bbox-in-tile pixels
@@ -411,26 +501,43 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
         const int thr01 = (fl & 2u) ? 0 : -1, thr12 = (fl & 4u) ? 0 : -1, thr20 = (fl & 8u) ? 0 : -1;
         const float s0x = r->s[0], s0y = r->s[1], s1x = r->s[2], s1y = r->s[3], s2x = r->s[4], s2y = r->s[5];
         const float r0 = r->rhw[0], r1 = r->rhw[1], r2 = r->rhw[2];
-        const float inv_bw = 1.0f / (float)bw;
+        // p -> (dx, dy): dy = floor((p + 0.5) / bw) via a 1-ulp reciprocal, exact for p < 1024, bw <= 32
+        const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
         const unsigned long long idlow = (unsigned long long)(t + 1u);
-        for (int p = lane; p < npx; p += 64) {
-            const int dy = (int)(((float)p + 0.5f) * inv_bw);   // exact for p < 1024, bw <= 32
-            const int dx = p - dy * bw;
-            const int E01 = (int)(E01o + A01 * (uint32_t)dx + B01 * (uint32_t)dy);
-            const int E12 = (int)(E12o + A12 * (uint32_t)dx + B12 * (uint32_t)dy);
-            const int E20 = (int)(E20o + A20 * (uint32_t)dx + B20 * (uint32_t)dy);
-            const bool covered = (E01 > thr01) & (E12 > thr12) & (E20 > thr20);
-            n_cov += (uint32_t)__popcll(__ballot(covered));
-            if (covered) {
-                const int cx = bx0 + dx, cy = by0 + dy;
-                Frag f = frag_eval(s0x, s0y, s1x, s1y, s2x, s2y, r0, r1, r2, cx, cy);
-                if (f.valid) {
-                    if (f.rhw != f.rhw) ++n_nan;
-                    const unsigned long long key = ((unsigned long long)zkey(f.rhw) << 32) | idlow;
-                    atomicMax(&s_key[(cy - ay0) * TILE + (cx - ax0)], key);
+        // Coefficients that fit 24 bits (always, unless the clipper produced far-away vertices) let the
+        // per-pixel edge update use full-rate v_mad_i32_i24; both forms are exact mod 2^32.
+        const uint32_t amax = max(max(max(A01 + 0x400000u, B01 + 0x400000u), max(A12 + 0x400000u, B12 + 0x400000u)),
+                                  max(A20 + 0x400000u, B20 + 0x400000u));
+        const bool fast24 = amax < 0x800000u;
+        auto sweep = [&](auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            for (int p = lane; p < npx; p += 64) {
+                const int dy = (int)(((float)p + 0.5f) * inv_bw);
+                const int dx = p - __mul24(dy, bw);
+                int E01, E12, E20;
+                if constexpr (FAST) {
+                    E01 = (int)E01o + __mul24((int)A01, dx) + __mul24((int)B01, dy);
+                    E12 = (int)E12o + __mul24((int)A12, dx) + __mul24((int)B12, dy);
+                    E20 = (int)E20o + __mul24((int)A20, dx) + __mul24((int)B20, dy);
+                } else {
+                    E01 = (int)(E01o + A01 * (uint32_t)dx + B01 * (uint32_t)dy);
+                    E12 = (int)(E12o + A12 * (uint32_t)dx + B12 * (uint32_t)dy);
+                    E20 = (int)(E20o + A20 * (uint32_t)dx + B20 * (uint32_t)dy);
+                }
+                const bool covered = (E01 > thr01) & (E12 > thr12) & (E20 > thr20);
+                n_cov += (uint32_t)__popcll(__ballot(covered));
+                if (covered) {
+                    const int cx = bx0 + dx, cy = by0 + dy;
+                    Frag f = frag_eval(s0x, s0y, s1x, s1y, s2x, s2y, r0, r1, r2, cx, cy);
+                    if (f.valid) {
+                        if (f.rhw != f.rhw) ++n_nan;
+                        const unsigned long long key = ((unsigned long long)zkey(f.rhw) << 32) | idlow;
+                        atomicMax(&s_key[(cy - ay0) * TILE + (cx - ax0)], key);
+                    }
                 }
             }
-        }
+        };
+        if (fast24) sweep(std::true_type{}); else sweep(std::false_type{});
     }
     if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
     if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
