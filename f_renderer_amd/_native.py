@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libfrr_hip.so")
-_SRC = [os.path.join(_HERE, "csrc", f) for f in ("frr_api.hip", "frr_kernels.h", "frr_device.h", "frr_exact.h")]
+_SRC = [os.path.join(_HERE, "csrc", f) for f in ("frr_api.hip", "frr_kernels.h", "frr_raster.h", "frr_device.h", "frr_exact.h")]
 _HDR = os.path.join(_ROOT, "include", "frr.h")
 
 HIPCC_FLAGS = [
@@ -115,6 +115,7 @@ SIGNATURES = {
     "frr_set_perspective": (None, [C.c_float, C.c_float, C.c_float, C.c_float, _P(C.c_float)]),
     "frr_debug_atan2f": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "frr_host_atan2f": (C.c_float, [C.c_float, C.c_float]),
+    "frr_debug_scan64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -60,6 +61,7 @@ struct frr_ctx {
     int geom_vs = -1;         // VS of the last frr_geometry
     uint64_t geom_ntris = 0;
     int rank = 0, world = 1;
+    bool raster_sweep = false; // FRR_RASTER=sweep: brute-force tile kernel instead of the span kernel
     hipEvent_t ev[16] = {};
     bool ev_set[16] = {};
     uint32_t prof_mask = 0;   // bit per KernelId
@@ -185,7 +187,13 @@ template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks
 template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uint32_t grid)
 {
     ProfScope p(c, KID_RASTER);
-    hipLaunchKernelGGL((k_raster<K, PS>), dim3(grid), dim3(256), 0, c->stream, a, c->duni);
+    if (c->raster_sweep) {
+        hipLaunchKernelGGL((k_raster<K, PS>), dim3(grid), dim3(256), 0, c->stream, a, c->duni);
+    } else {
+        // the span algebra needs every coordinate it touches within +-SPAN_SAFE (no i32 wrap)
+        const int win_safe = a.x0 >= -SPAN_SAFE && a.y0 >= -SPAN_SAFE && a.x1 <= SPAN_SAFE && a.y1 <= SPAN_SAFE;
+        hipLaunchKernelGGL((k_raster_span<K, PS>), dim3(grid), dim3(256), 0, c->stream, a, c->duni, win_safe);
+    }
 }
 
 } // namespace
@@ -230,6 +238,7 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     if (hipSetDevice(device) != hipSuccess) return FRR_ERR_HIP;
     frr_ctx *c = new frr_ctx();
     c->device = device; c->W = width; c->H = height;
+    { const char *e = getenv("FRR_RASTER"); c->raster_sweep = e && strcmp(e, "sweep") == 0; }
     if (stream) c->stream = (hipStream_t)stream;
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FRR_ERR_HIP; } c->own_stream = true; }
     const size_t npx = (size_t)width * height;
@@ -640,6 +649,23 @@ void frr_set_perspective(float fovy, float aspect, float zn, float zf, float m[1
 
 // ---- debug hooks ------------------------------------------------------------------------------
 float frr_host_atan2f(float y, float x) { return fd_atan2f(y, x); }
+
+int frr_debug_scan64(frr_ctx *c, const uint32_t *in, uint32_t *out)
+{
+    if (!c || !in || !out) return FRR_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t *d = nullptr;
+    if (hipMalloc((void **)&d, 128 * 4) != hipSuccess) return fail(c, FRR_ERR_NOMEM, "hipMalloc");
+    hipError_t e = hipMemcpyAsync(d, in, 64 * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_scan, dim3(1), dim3(64), 0, c->stream, d, d + 64);
+        e = hipMemcpyAsync(out, d + 64, 64 * 4, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, FRR_ERR_HIP, hipGetErrorString(e));
+    return FRR_OK;
+}
 
 int frr_debug_atan2f(frr_ctx *c, const float *y, const float *x, float *out, uint64_t n)
 {

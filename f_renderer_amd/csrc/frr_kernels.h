@@ -433,149 +433,9 @@ __global__ __launch_bounds__(256) void k_bin_colscan(uint32_t *__restrict__ M, u
     for (uint32_t g = gs; g < G; g += 8) if (ok) M[(size_t)g * ntiles + t] = s[g][tl];
 }
 
-// ---------------------------------------------------------------------------------------------
-// K3 tile raster + resolve.  One workgroup (4 waves) per 32x32 tile; per-pixel 64-bit keys
-// (zkey(rhw) << 32 | triangle+1) live in LDS.  One triangle per wavefront: the wave loads the
-// triangle's 64-byte record with scalar loads, its 64 lanes sweep the bbox-in-tile pixels
-// (packed row-major, 64 per step), evaluate the integer edge functions (renderer.rs:329-341),
-// the float barycentrics and rhw (:343-360), and resolve the z-test (:363-366) with an LDS
-// atomic max: argmax over (rhw, emission index) is exactly the sequential rule "later fragment
-// wins ties" (SURVEY A.6).  After the last triangle each pixel's winner is re-evaluated, shaded
-// (:368-381) and stored with row-contiguous stores.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int xcd_remap(int bid, int nwg)
-{
-    // blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of tiles so
-    // neighbouring tiles (which share triangle records) share an L2.  Bijective for any nwg.
-    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-}
-
-template <int K, int PS>
-__global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
-{
-    __shared__ unsigned long long s_key[TILE_PX];
-    const int tid = threadIdx.x;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx = bid % a.tiles_x;
-    const int ty = a.rank + (bid / a.tiles_x) * a.world;
-    const int tile = ty * a.tiles_x + tx;
-    const int lx0 = tx * TILE, ly0 = ty * TILE;                 // window-local tile origin
-    const int tw = min(TILE, a.win_w - lx0), th = min(TILE, a.win_h - ly0);
-    const uint32_t beg = a.tile_offsets[tile], end = min(a.tile_offsets[tile + 1], a.bin_cap);
-    if (beg >= end) return; // nothing binned here: colour, depth and ids stay as they are
-
-    for (int i = tid; i < TILE_PX; i += 256) {
-        const int x = i & (TILE - 1), y = i >> 5;
-        float d = 0.0f;
-        if (x < tw && y < th) d = a.depth[(size_t)(ly0 + y) * a.dstride + (lx0 + x)];
-        s_key[i] = (unsigned long long)zkey(d) << 32;
-    }
-    __syncthreads();
-
-    const int lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ax0 = a.x0 + lx0, ay0 = a.y0 + ly0;               // absolute pixel of the tile origin
-    uint32_t n_cov = 0, n_nan = 0;
-    for (uint32_t e = beg + wave; e < end; e += 4) {
-        const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e]);
-        const RasterRec *__restrict__ r = a.recs + t;
-        const int p0x = r->p[0], p0y = r->p[1], p1x = r->p[2], p1y = r->p[3], p2x = r->p[4], p2y = r->p[5];
-        // clamped bbox (renderer.rs:285-298; clamp is monotone so it commutes with min/max)
-        int bx0 = clampi(min(p0x, min(p1x, p2x)), a.x0, a.x1), bx1 = clampi(max(p0x, max(p1x, p2x)), a.x0, a.x1);
-        int by0 = clampi(min(p0y, min(p1y, p2y)), a.y0, a.y1), by1 = clampi(max(p0y, max(p1y, p2y)), a.y0, a.y1);
-        bx0 = max(bx0, ax0); bx1 = min(bx1, ax0 + tw);          // ... intersected with this tile
-        by0 = max(by0, ay0); by1 = min(by1, ay0 + th);
-        const int bw = bx1 - bx0, bh = by1 - by0;
-        if (bw <= 0 || bh <= 0) continue;
-        const int npx = bw * bh;
-        // edge functions E = A*(cx - px) + B*(cy - py) in wrapping i32 (renderer.rs:329-331)
-        const uint32_t A01 = 0u - (uint32_t)(p1y - p0y), B01 = (uint32_t)(p1x - p0x);
-        const uint32_t A12 = 0u - (uint32_t)(p2y - p1y), B12 = (uint32_t)(p2x - p1x);
-        const uint32_t A20 = 0u - (uint32_t)(p0y - p2y), B20 = (uint32_t)(p0x - p2x);
-        const uint32_t E01o = A01 * (uint32_t)(bx0 - p0x) + B01 * (uint32_t)(by0 - p0y);
-        const uint32_t E12o = A12 * (uint32_t)(bx0 - p1x) + B12 * (uint32_t)(by0 - p1y);
-        const uint32_t E20o = A20 * (uint32_t)(bx0 - p2x) + B20 * (uint32_t)(by0 - p2y);
-        const uint32_t fl = r->flags;
-        // reject E < bias  <=>  accept E > bias-1   (bias 0 for top-left edges, else 1; :333-341)
-        const int thr01 = (fl & 2u) ? 0 : -1, thr12 = (fl & 4u) ? 0 : -1, thr20 = (fl & 8u) ? 0 : -1;
-        const float s0x = r->s[0], s0y = r->s[1], s1x = r->s[2], s1y = r->s[3], s2x = r->s[4], s2y = r->s[5];
-        const float r0 = r->rhw[0], r1 = r->rhw[1], r2 = r->rhw[2];
-        // p -> (dx, dy): dy = floor((p + 0.5) / bw) via a 1-ulp reciprocal, exact for p < 1024, bw <= 32
-        const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
-        const unsigned long long idlow = (unsigned long long)(t + 1u);
-        // Coefficients that fit 24 bits (always, unless the clipper produced far-away vertices) let the
-        // per-pixel edge update use full-rate v_mad_i32_i24; both forms are exact mod 2^32.
-        const uint32_t amax = max(max(max(A01 + 0x400000u, B01 + 0x400000u), max(A12 + 0x400000u, B12 + 0x400000u)),
-                                  max(A20 + 0x400000u, B20 + 0x400000u));
-        const bool fast24 = amax < 0x800000u;
-        auto sweep = [&](auto fast_tag) {
-            constexpr bool FAST = decltype(fast_tag)::value;
-            for (int p = lane; p < npx; p += 64) {
-                const int dy = (int)(((float)p + 0.5f) * inv_bw);
-                const int dx = p - __mul24(dy, bw);
-                int E01, E12, E20;
-                if constexpr (FAST) {
-                    E01 = (int)E01o + __mul24((int)A01, dx) + __mul24((int)B01, dy);
-                    E12 = (int)E12o + __mul24((int)A12, dx) + __mul24((int)B12, dy);
-                    E20 = (int)E20o + __mul24((int)A20, dx) + __mul24((int)B20, dy);
-                } else {
-                    E01 = (int)(E01o + A01 * (uint32_t)dx + B01 * (uint32_t)dy);
-                    E12 = (int)(E12o + A12 * (uint32_t)dx + B12 * (uint32_t)dy);
-                    E20 = (int)(E20o + A20 * (uint32_t)dx + B20 * (uint32_t)dy);
-                }
-                const bool covered = (E01 > thr01) & (E12 > thr12) & (E20 > thr20);
-                n_cov += (uint32_t)__popcll(__ballot(covered));
-                if (covered) {
-                    const int cx = bx0 + dx, cy = by0 + dy;
-                    Frag f = frag_eval(s0x, s0y, s1x, s1y, s2x, s2y, r0, r1, r2, cx, cy);
-                    if (f.valid) {
-                        if (f.rhw != f.rhw) ++n_nan;
-                        const unsigned long long key = ((unsigned long long)zkey(f.rhw) << 32) | idlow;
-                        atomicMax(&s_key[(cy - ay0) * TILE + (cx - ax0)], key);
-                    }
-                }
-            }
-        };
-        if (fast24) sweep(std::true_type{}); else sweep(std::false_type{});
-    }
-    if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
-    if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
-    __syncthreads();
-
-    // resolve: the owner of each pixel is re-evaluated with the same arithmetic and written out
-    const uint32_t tri_base = a.cnt->tri_base;
-    for (int i = tid; i < TILE_PX; i += 256) {
-        const int x = i & (TILE - 1), y = i >> 5;
-        if (x >= tw || y >= th) continue;
-        const uint32_t id = (uint32_t)s_key[i];
-        if (id == 0u) continue; // existing depth won (or nothing covered this pixel)
-        const uint32_t t = id - 1u;
-        const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + t);
-        const uint4 q1 = rp[1], q2 = rp[2], q3 = rp[3];
-        const int cx = ax0 + x, cy = ay0 + y;
-        const float r0 = u2f(q3.x), r1 = u2f(q3.y), r2 = u2f(q3.z);
-        Frag f = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), r0, r1, r2, cx, cy);
-        const size_t di = (size_t)(ly0 + y) * a.dstride + (lx0 + x);
-        a.depth[di] = f.rhw;                                                    // :366
-        a.tri_id[di] = tri_base + t;
-        if constexpr (PS != FRR_PS_DEPTH) {
-            const float w = 1.0f / (f.rhw != 0.0f ? f.rhw : 1.0f);              // :368
-            const float c0 = r0 * f.a * w, c1 = r1 * f.b * w, c2 = r2 * f.c * w; // :370-372
-            float in[K > 0 ? K : 1];
-            if constexpr (K > 0) {
-                const float *v = a.vary + (size_t)t * (3 * K);
-#pragma unroll
-                for (int k = 0; k < K; ++k) in[k] = v[k] * c0 + v[K + k] * c1 + v[2 * K + k] * c2; // :374-378
-            }
-            float col[4];
-            run_ps<PS>(u, in, col);                                             // :380
-            const uint32_t q = quantize_u8(col[0]) | (quantize_u8(col[1]) << 8) | (quantize_u8(col[2]) << 16) |
-                               (quantize_u8(col[3]) << 24);                     // :7-14
-            reinterpret_cast<uint32_t *>(a.color)[(size_t)(ly0 + y) * a.cstride + (lx0 + x)] = q; // :381,:496-503
-        }
-    }
-}
+} // namespace frr
+#include "frr_raster.h"
+namespace frr {
 
 // ---- debug --------------------------------------------------------------------------------
 __global__ void k_debug_atan2f(const float *y, const float *x, float *out, uint64_t n)

@@ -1,0 +1,419 @@
+// frr_raster.h -- K3: tile raster + resolve kernels (wave64, LDS keys).
+//
+// One workgroup (4 waves) per 32x32 screen tile.  Per-pixel 64-bit keys
+//   zkey(rhw) << 32 | (triangle index + 1)
+// live in LDS and are resolved with ds_max_u64: argmax over (rhw, emission index) is exactly the
+// reference's sequential rule "`rhw < depth` rejects, ties go to the later triangle"
+// (renderer.rs:363-366), so waves may race and bins may be unordered.  After the last
+// triangle each pixel's winner is re-evaluated with the same arithmetic, shaded (:368-381) and
+// stored row-contiguously.
+//
+// Two coverage strategies produce the same fragment set {pixels passing renderer.rs:329-341}:
+//   k_raster       one triangle per wavefront, brute-force sweep of bbox-in-tile pixels (64/step);
+//   k_raster_span  64 triangles per wavefront-batch: exact per-row spans from the integer edge
+//                  functions, then fragments packed 64 per step (no lane idles on uncovered bbox
+//                  pixels).  Triangles whose coordinates could overflow i32 in the span algebra
+//                  (|spi| > 8192, only the clipper's far-away vertices) take the brute-force sweep,
+//                  which is exact under wrapping arithmetic.
+#pragma once
+#include "frr_device.h"
+#include <type_traits>
+
+namespace frr {
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    // blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of tiles so
+    // neighbouring tiles (which share triangle records) share an L2.  Bijective for any nwg.
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+}
+
+struct TileCtx {
+    int tile, lx0, ly0, tw, th, ax0, ay0; // window-local origin, extent, absolute pixel origin
+    uint32_t beg, end;
+};
+
+__device__ __forceinline__ TileCtx tile_ctx(const RasterArgs &a)
+{
+    TileCtx c;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = bid % a.tiles_x;
+    const int ty = a.rank + (bid / a.tiles_x) * a.world;
+    c.tile = ty * a.tiles_x + tx;
+    c.lx0 = tx * TILE; c.ly0 = ty * TILE;
+    c.tw = min(TILE, a.win_w - c.lx0); c.th = min(TILE, a.win_h - c.ly0);
+    c.ax0 = a.x0 + c.lx0; c.ay0 = a.y0 + c.ly0;
+    c.beg = a.tile_offsets[c.tile];
+    c.end = min(a.tile_offsets[c.tile + 1], a.bin_cap);
+    return c;
+}
+
+// keys <- current depth buffer (index 0 = "what is already there")
+__device__ __forceinline__ void tile_load_keys(const RasterArgs &a, const TileCtx &c, unsigned long long *s_key)
+{
+    for (int i = threadIdx.x; i < TILE_PX; i += 256) {
+        const int x = i & (TILE - 1), y = i >> 5;
+        float d = 0.0f;
+        if (x < c.tw && y < c.th) d = a.depth[(size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x)];
+        s_key[i] = (unsigned long long)zkey(d) << 32;
+    }
+}
+
+// resolve: the owner of each pixel is re-evaluated with the same arithmetic and written out
+template <int K, int PS>
+__device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUniforms &u, const TileCtx &c,
+                                             const unsigned long long *s_key)
+{
+    const uint32_t tri_base = a.cnt->tri_base;
+    for (int i = threadIdx.x; i < TILE_PX; i += 256) {
+        const int x = i & (TILE - 1), y = i >> 5;
+        if (x >= c.tw || y >= c.th) continue;
+        const uint32_t id = (uint32_t)s_key[i];
+        if (id == 0u) continue; // existing depth won (or nothing covered this pixel)
+        const uint32_t t = id - 1u;
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + t);
+        const uint4 q1 = rp[1], q2 = rp[2], q3 = rp[3];
+        const int cx = c.ax0 + x, cy = c.ay0 + y;
+        const float r0 = u2f(q3.x), r1 = u2f(q3.y), r2 = u2f(q3.z);
+        Frag f = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), r0, r1, r2, cx, cy);
+        const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
+        a.depth[di] = f.rhw;                                                    // :366
+        a.tri_id[di] = tri_base + t;
+        if constexpr (PS != FRR_PS_DEPTH) {
+            const float w = 1.0f / (f.rhw != 0.0f ? f.rhw : 1.0f);              // :368
+            const float c0 = r0 * f.a * w, c1 = r1 * f.b * w, c2 = r2 * f.c * w; // :370-372
+            float in[K > 0 ? K : 1];
+            if constexpr (K > 0) {
+                const float *v = a.vary + (size_t)t * (3 * K);
+#pragma unroll
+                for (int k = 0; k < K; ++k) in[k] = v[k] * c0 + v[K + k] * c1 + v[2 * K + k] * c2; // :374-378
+            }
+            float col[4];
+            run_ps<PS>(u, in, col);                                             // :380
+            const uint32_t q = quantize_u8(col[0]) | (quantize_u8(col[1]) << 8) | (quantize_u8(col[2]) << 16) |
+                               (quantize_u8(col[3]) << 24);                     // :7-14
+            reinterpret_cast<uint32_t *>(a.color)[(size_t)(c.ly0 + y) * a.cstride + (c.lx0 + x)] = q; // :381,:496-503
+        }
+    }
+}
+
+// Brute-force sweep of ONE triangle (wave-uniform index t) by the whole wave: every pixel of
+// bbox-in-tile is tested with the wrapping-i32 edge functions of renderer.rs:329-341.
+__device__ __forceinline__ void sweep_triangle(const RasterArgs &a, const TileCtx &c, uint32_t t, int lane,
+                                               unsigned long long *s_key, uint32_t &n_cov, uint32_t &n_nan)
+{
+    const RasterRec *__restrict__ r = a.recs + t;
+    const int p0x = r->p[0], p0y = r->p[1], p1x = r->p[2], p1y = r->p[3], p2x = r->p[4], p2y = r->p[5];
+    // clamped bbox (renderer.rs:285-298; clamp is monotone so it commutes with min/max)
+    int bx0 = clampi(min(p0x, min(p1x, p2x)), a.x0, a.x1), bx1 = clampi(max(p0x, max(p1x, p2x)), a.x0, a.x1);
+    int by0 = clampi(min(p0y, min(p1y, p2y)), a.y0, a.y1), by1 = clampi(max(p0y, max(p1y, p2y)), a.y0, a.y1);
+    bx0 = max(bx0, c.ax0); bx1 = min(bx1, c.ax0 + c.tw);        // ... intersected with this tile
+    by0 = max(by0, c.ay0); by1 = min(by1, c.ay0 + c.th);
+    const int bw = bx1 - bx0, bh = by1 - by0;
+    if (bw <= 0 || bh <= 0) return;
+    const int npx = bw * bh;
+    // edge functions E = A*(cx - px) + B*(cy - py) in wrapping i32 (renderer.rs:329-331)
+    const uint32_t A01 = 0u - (uint32_t)(p1y - p0y), B01 = (uint32_t)(p1x - p0x);
+    const uint32_t A12 = 0u - (uint32_t)(p2y - p1y), B12 = (uint32_t)(p2x - p1x);
+    const uint32_t A20 = 0u - (uint32_t)(p0y - p2y), B20 = (uint32_t)(p0x - p2x);
+    const uint32_t E01o = A01 * (uint32_t)(bx0 - p0x) + B01 * (uint32_t)(by0 - p0y);
+    const uint32_t E12o = A12 * (uint32_t)(bx0 - p1x) + B12 * (uint32_t)(by0 - p1y);
+    const uint32_t E20o = A20 * (uint32_t)(bx0 - p2x) + B20 * (uint32_t)(by0 - p2y);
+    const uint32_t fl = r->flags;
+    // reject E < bias  <=>  accept E > bias-1   (bias 0 for top-left edges, else 1; :333-341)
+    const int thr01 = (fl & 2u) ? 0 : -1, thr12 = (fl & 4u) ? 0 : -1, thr20 = (fl & 8u) ? 0 : -1;
+    const float s0x = r->s[0], s0y = r->s[1], s1x = r->s[2], s1y = r->s[3], s2x = r->s[4], s2y = r->s[5];
+    const float r0 = r->rhw[0], r1 = r->rhw[1], r2 = r->rhw[2];
+    // p -> (dx, dy): dy = floor((p + 0.5) / bw) via a 1-ulp reciprocal, exact for p < 1024, bw <= 32
+    const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
+    const unsigned long long idlow = (unsigned long long)(t + 1u);
+    for (int p = lane; p < npx; p += 64) {
+        const int dy = (int)(((float)p + 0.5f) * inv_bw);
+        const int dx = p - __mul24(dy, bw);
+        const int E01 = (int)(E01o + A01 * (uint32_t)dx + B01 * (uint32_t)dy);
+        const int E12 = (int)(E12o + A12 * (uint32_t)dx + B12 * (uint32_t)dy);
+        const int E20 = (int)(E20o + A20 * (uint32_t)dx + B20 * (uint32_t)dy);
+        const bool covered = (E01 > thr01) & (E12 > thr12) & (E20 > thr20);
+        n_cov += (uint32_t)__popcll(__ballot(covered));
+        if (covered) {
+            const int cx = bx0 + dx, cy = by0 + dy;
+            Frag f = frag_eval(s0x, s0y, s1x, s1y, s2x, s2y, r0, r1, r2, cx, cy);
+            if (f.valid) {
+                if (f.rhw != f.rhw) ++n_nan;
+                const unsigned long long key = ((unsigned long long)zkey(f.rhw) << 32) | idlow;
+                atomicMax(&s_key[(cy - c.ay0) * TILE + (cx - c.ax0)], key);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_raster: one triangle per wavefront (brute force).  Kept as the reference form of the tile
+// kernel (FRR_RASTER=sweep) and as the exact path for wrapping coordinates.
+// ---------------------------------------------------------------------------------------------
+template <int K, int PS>
+__global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
+{
+    __shared__ unsigned long long s_key[TILE_PX];
+    const TileCtx c = tile_ctx(a);
+    if (c.beg >= c.end) return; // nothing binned here: colour, depth and ids stay as they are
+    tile_load_keys(a, c, s_key);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t n_cov = 0, n_nan = 0;
+    for (uint32_t e = c.beg + wave; e < c.end; e += 4) {
+        const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e]);
+        sweep_triangle(a, c, t, lane, s_key, n_cov, n_nan);
+    }
+    if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
+    if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
+    __syncthreads();
+    tile_resolve<K, PS>(a, u, c, s_key);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_raster_span
+// ---------------------------------------------------------------------------------------------
+constexpr int SPAN_SAFE = 8192; // |spi| and window coordinates up to this keep every edge value < 2^30
+
+// wave64 inclusive prefix sum on the DPP network (row_shr within 16-lane rows, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x)
+{
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// all LDS traffic of a wave is in order; this only stops the compiler from moving accesses across
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// A 64-bit "heads" mask marks where segments start inside a window of 64 consecutive items.
+// For lane L: k = number of heads at positions <= L, off = distance to the nearest head at or
+// before L (or L + carry when the segment started in an earlier window).
+struct SegPos { int k, off; };
+__device__ __forceinline__ SegPos seg_locate(uint32_t h_lo, uint32_t h_hi, uint32_t le_lo, uint32_t le_hi, int lane, int carry)
+{
+    const uint32_t m_lo = h_lo & le_lo, m_hi = h_hi & le_hi;
+    SegPos s;
+    s.k = __popc(m_lo) + __popc(m_hi);
+    const int hp = m_hi ? 63 - __clz((int)m_hi) : (m_lo ? 31 - __clz((int)m_lo) : -1);
+    s.off = hp >= 0 ? lane - hp : lane + carry;
+    return s;
+}
+
+struct alignas(16) TriI {     // per-triangle integers staged for the span phase
+    int32_t e01, e12, e20;    // edge values at the bbox-in-tile origin
+    uint32_t ab01, ab12, ab20; // A (low 16, signed) | B (high 16, signed)
+    uint32_t misc;            // bx0l:5 | by0l:5 <<5 | bw:6 <<10 | bias bits <<16
+    uint32_t id;              // triangle index + 1
+};
+struct alignas(16) TriF { float s0x, s0y, s1x, s1y, s2x, s2y, r0, r1, r2, pad0, pad1, pad2; };
+
+// dx in [lo,hi) with  Er + A*dx > thr  (thr in {-1,0}); exact floor division, see DESIGN.md
+__device__ __forceinline__ void edge_bound(int Er, int A, int thr, int &lo, int &hi)
+{
+    const int N = (thr + 1) - Er; // need A*dx >= N
+    if (A == 0) { if (N > 0) hi = 0; return; }
+    const int D = A > 0 ? A : -A;
+    const int M = A > 0 ? N + D - 1 : -N;           // A>0: dx >= ceil(N/A) = floor(M/D); A<0: dx <= floor(M/D)
+    float qf = (float)M * __builtin_amdgcn_rcpf((float)D);
+    qf = fminf(fmaxf(qf, -2.0f), 40.0f);            // only quotients in [0, 32] matter
+    int q = (int)qf;
+    const int r = M - __mul24(q, D);
+    q += (r < 0) ? -1 : ((r >= D) ? 1 : 0);         // one correction step makes the in-range quotient exact
+    if (A > 0) lo = max(lo, q); else hi = min(hi, q + 1);
+}
+
+template <int K, int PS>
+__global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u, int win_safe)
+{
+    __shared__ unsigned long long s_key[TILE_PX];
+    __shared__ TriI s_ti[4][64];
+    __shared__ TriF s_tf[4][64];
+    __shared__ uint32_t s_hrow[4][64];  // heads of (triangle -> rows)
+    __shared__ uint32_t s_hfrag[4][64]; // heads of (span -> fragments)
+    __shared__ uint32_t s_q[4][64];     // compacted span descriptors
+    __shared__ uint32_t s_next;
+    const TileCtx c = tile_ctx(a);
+    if (c.beg >= c.end) return;
+    tile_load_keys(a, c, s_key);
+    if (threadIdx.x == 0) s_next = 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t le_lo = lane < 32 ? (2u << lane) - 1u : 0xFFFFFFFFu;
+    const uint32_t le_hi = lane < 32 ? 0u : (2u << (lane - 32)) - 1u;
+    uint32_t n_cov = 0, n_nan = 0;
+
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&s_next, 1u);
+        b = __builtin_amdgcn_readfirstlane(b);
+        const uint32_t e0 = c.beg + b * 64u;
+        if (e0 >= c.end) break;
+        const int nb = (int)min(64u, c.end - e0);
+
+        // ---- phase 1: lane = triangle.  Record -> bbox-in-tile, edge coefficients, staging ----
+        const bool valid = lane < nb;
+        const uint32_t t = valid ? a.bins[e0 + lane] : 0u;
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + t);
+        const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+        const int p0x = (int)q0.x, p0y = (int)q0.y, p1x = (int)q0.z, p1y = (int)q0.w, p2x = (int)q1.x, p2y = (int)q1.y;
+        int bx0 = clampi(min(p0x, min(p1x, p2x)), a.x0, a.x1), bx1 = clampi(max(p0x, max(p1x, p2x)), a.x0, a.x1);
+        int by0 = clampi(min(p0y, min(p1y, p2y)), a.y0, a.y1), by1 = clampi(max(p0y, max(p1y, p2y)), a.y0, a.y1);
+        bx0 = max(bx0, c.ax0); bx1 = min(bx1, c.ax0 + c.tw);
+        by0 = max(by0, c.ay0); by1 = min(by1, c.ay0 + c.th);
+        const int bw = bx1 - bx0, bh = by1 - by0;
+        const int amax = max(max(max(abs(p0x), abs(p0y)), max(abs(p1x), abs(p1y))), max(abs(p2x), abs(p2y)));
+        const bool nonempty = valid && bw > 0 && bh > 0;
+        const bool safe = nonempty && win_safe && amax <= SPAN_SAFE;
+        const unsigned long long unsafe_mask = __ballot(nonempty && !safe);
+        const uint32_t rows = safe ? (uint32_t)bh : 0u;
+        {
+            // wrapping arithmetic (values are only meaningful, and only used, for `safe` triangles)
+            const uint32_t A01 = 0u - (uint32_t)(p1y - p0y), B01 = (uint32_t)(p1x - p0x);
+            const uint32_t A12 = 0u - (uint32_t)(p2y - p1y), B12 = (uint32_t)(p2x - p1x);
+            const uint32_t A20 = 0u - (uint32_t)(p0y - p2y), B20 = (uint32_t)(p0x - p2x);
+            TriI ti;
+            ti.e01 = (int)(A01 * (uint32_t)(bx0 - p0x) + B01 * (uint32_t)(by0 - p0y));
+            ti.e12 = (int)(A12 * (uint32_t)(bx0 - p1x) + B12 * (uint32_t)(by0 - p1y));
+            ti.e20 = (int)(A20 * (uint32_t)(bx0 - p2x) + B20 * (uint32_t)(by0 - p2y));
+            ti.ab01 = (A01 & 0xFFFFu) | (B01 << 16);
+            ti.ab12 = (A12 & 0xFFFFu) | (B12 << 16);
+            ti.ab20 = (A20 & 0xFFFFu) | (B20 << 16);
+            ti.misc = (uint32_t)(bx0 - c.ax0) | ((uint32_t)(by0 - c.ay0) << 5) | ((uint32_t)bw << 10) | (((q3.w >> 1) & 7u) << 16);
+            ti.id = t + 1u;
+            if (safe) s_ti[w][lane] = ti;
+            TriF tf;
+            tf.s0x = u2f(q1.z); tf.s0y = u2f(q1.w); tf.s1x = u2f(q2.x); tf.s1y = u2f(q2.y);
+            tf.s2x = u2f(q2.z); tf.s2y = u2f(q2.w); tf.r0 = u2f(q3.x); tf.r1 = u2f(q3.y); tf.r2 = u2f(q3.z);
+            tf.pad0 = tf.pad1 = tf.pad2 = 0.0f;
+            if (safe) s_tf[w][lane] = tf;
+        }
+        // rows of all triangles laid end to end: heads mark where each triangle's rows start
+        const uint32_t rincl = wave_incl_scan_dpp(rows);
+        const int R = (int)__builtin_amdgcn_readlane((int)rincl, 63);
+        s_hrow[w][lane] = 0u;
+        wave_lds_fence();
+        if (rows) { const uint32_t st = rincl - rows; atomicOr(&s_hrow[w][st >> 5], 1u << (st & 31)); }
+        wave_lds_fence();
+        // compact index of each safe triangle (heads are counted, so triangles are addressed by rank)
+        const unsigned long long safe_mask = __ballot(rows != 0u);
+        const int trank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(safe_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)safe_mask, 0u));
+        if (rows) s_q[w][trank] = (uint32_t)lane; // rank -> lane (reuses s_q before the span phase needs it)
+        wave_lds_fence();
+        uint32_t tri_of_rank = s_q[w][lane];      // lane L holds the lane index of the L-th safe triangle
+        wave_lds_fence();
+
+        int jbase = 0, jcarry = 0; // heads seen in earlier row windows; rows of the open triangle already done
+        for (int r0 = 0; r0 < R; r0 += 64) {
+            // ---- phase 2: lane = (triangle, row).  Exact covered span of that row. ----
+            const uint32_t h_lo = __builtin_amdgcn_readfirstlane(s_hrow[w][r0 >> 5]);
+            const uint32_t h_hi = __builtin_amdgcn_readfirstlane(s_hrow[w][(r0 >> 5) + 1 < 64 ? (r0 >> 5) + 1 : 63]) & ((r0 >> 5) + 1 < 64 ? ~0u : 0u);
+            const SegPos sp = seg_locate(h_lo, h_hi, le_lo, le_hi, lane, jcarry);
+            const bool ractive = r0 + lane < R;
+            const int jr = jbase + sp.k - 1;                                   // rank of the triangle
+            const int j = __shfl((int)tri_of_rank, ractive ? jr : 0);          // its staging slot (lane of phase 1)
+            int len = 0, xl = 0, yl = 0;
+            if (ractive) {
+                const TriI ti = s_ti[w][j];
+                const int row = sp.off;
+                const int bwj = (int)((ti.misc >> 10) & 63u);
+                const int A01 = (int)(ti.ab01 << 16) >> 16, B01 = (int)ti.ab01 >> 16;
+                const int A12 = (int)(ti.ab12 << 16) >> 16, B12 = (int)ti.ab12 >> 16;
+                const int A20 = (int)(ti.ab20 << 16) >> 16, B20 = (int)ti.ab20 >> 16;
+                int lo = 0, hi = bwj;
+                edge_bound(ti.e01 + __mul24(B01, row), A01, (ti.misc & (1u << 16)) ? 0 : -1, lo, hi);
+                edge_bound(ti.e12 + __mul24(B12, row), A12, (ti.misc & (1u << 17)) ? 0 : -1, lo, hi);
+                edge_bound(ti.e20 + __mul24(B20, row), A20, (ti.misc & (1u << 18)) ? 0 : -1, lo, hi);
+                len = max(hi - lo, 0);
+                xl = (int)(ti.misc & 31u) + lo;
+                yl = (int)((ti.misc >> 5) & 31u) + row;
+            }
+            // next window's carry-in for the row heads
+            {
+                const int nh = __popc(h_lo) + __popc(h_hi);
+                const int last = h_hi ? 63 - __clz((int)h_hi) : (h_lo ? 31 - __clz((int)h_lo) : -1);
+                jcarry = last >= 0 ? 64 - last : jcarry + 64;
+                jbase += nh;
+            }
+            // ---- spans of this window laid end to end: heads mark where each span's fragments start ----
+            const unsigned long long nz = __ballot(len > 0);
+            if (nz == 0ull) continue;
+            const int srank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
+            const uint32_t fincl = wave_incl_scan_dpp((uint32_t)len);
+            const int F = (int)__builtin_amdgcn_readlane((int)fincl, 63);
+            s_hfrag[w][lane] = 0u;
+            wave_lds_fence();
+            if (len > 0) {
+                const uint32_t st = fincl - (uint32_t)len;
+                atomicOr(&s_hfrag[w][st >> 5], 1u << (st & 31));
+                s_q[w][srank] = (uint32_t)j | ((uint32_t)yl << 6) | ((uint32_t)xl << 11); // span descriptor
+            }
+            wave_lds_fence();
+            n_cov += (uint32_t)F;
+
+            // ---- phase 3: lane = fragment.  Barycentrics, rhw, z key, LDS atomic max ----
+            int qbase = 0, qcarry = 0;
+            for (int f0 = 0; f0 < F; f0 += 64) {
+                const uint32_t g_lo = __builtin_amdgcn_readfirstlane(s_hfrag[w][f0 >> 5]);
+                const uint32_t g_hi = __builtin_amdgcn_readfirstlane(s_hfrag[w][(f0 >> 5) + 1 < 64 ? (f0 >> 5) + 1 : 63]) & ((f0 >> 5) + 1 < 64 ? ~0u : 0u);
+                const SegPos fp = seg_locate(g_lo, g_hi, le_lo, le_hi, lane, qcarry);
+                if (f0 + lane < F) {
+                    const uint32_t d = s_q[w][qbase + fp.k - 1];
+                    const int sj = (int)(d & 63u), y = (int)((d >> 6) & 31u), x = (int)((d >> 11) & 31u) + fp.off;
+                    const TriF tf = s_tf[w][sj];
+                    const uint32_t id = s_ti[w][sj].id;
+                    Frag f = frag_eval(tf.s0x, tf.s0y, tf.s1x, tf.s1y, tf.s2x, tf.s2y, tf.r0, tf.r1, tf.r2, c.ax0 + x, c.ay0 + y);
+                    if (f.valid) {
+                        if (f.rhw != f.rhw) ++n_nan;
+                        const unsigned long long key = ((unsigned long long)zkey(f.rhw) << 32) | (unsigned long long)id;
+                        atomicMax(&s_key[y * TILE + x], key);
+                    }
+                }
+                const int nh = __popc(g_lo) + __popc(g_hi);
+                const int last = g_hi ? 63 - __clz((int)g_hi) : (g_lo ? 31 - __clz((int)g_lo) : -1);
+                qcarry = last >= 0 ? 64 - last : qcarry + 64;
+                qbase += nh;
+            }
+            wave_lds_fence(); // s_q / s_hfrag are rewritten by the next row window
+        }
+
+        // ---- triangles outside the span algebra's safe range: exact brute-force sweep ----
+        unsigned long long um = unsafe_mask;
+        while (um) {
+            const int src = __builtin_ctzll(um);
+            um &= um - 1;
+            const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)t, src);
+            uint32_t ncv = 0;
+            sweep_triangle(a, c, tu, lane, s_key, ncv, n_nan);
+            n_cov += ncv;
+        }
+        wave_lds_fence(); // staging is rewritten by the next batch
+    }
+    if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
+    if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
+    __syncthreads();
+    tile_resolve<K, PS>(a, u, c, s_key);
+}
+
+// debug: the DPP scan against a serial sum (tests)
+__global__ void k_debug_scan(const uint32_t *in, uint32_t *out)
+{
+    out[threadIdx.x] = wave_incl_scan_dpp(in[threadIdx.x]);
+}
+
+} // namespace frr

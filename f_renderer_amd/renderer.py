@@ -283,6 +283,13 @@ class Renderer:
         self._check(self._lib.frr_profile_get(self._ctx, kernel.encode(), C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def debug_scan64(self, values):
+        v = np.ascontiguousarray(values, np.uint32)
+        assert v.size == 64
+        out = np.empty(64, np.uint32)
+        self._check(self._lib.frr_debug_scan64(self._ctx, v.ctypes.data, out.ctypes.data))
+        return out
+
     def debug_atan2f(self, y, x):
         y = np.ascontiguousarray(y, np.float32)
         x = np.ascontiguousarray(x, np.float32)

@@ -313,3 +313,30 @@ def test_device_atan2f_matches_glibc(oracle):
     np.testing.assert_array_equal(got[:20000].view(np.uint32), exp.view(np.uint32))
     host = np.array([fr.lib().frr_host_atan2f(float(a), float(b)) for a, b in zip(y[:20000], x[:20000])], np.float32)
     np.testing.assert_array_equal(host.view(np.uint32), exp.view(np.uint32))
+
+
+def test_wave_scan_dpp():
+    """The DPP wave64 inclusive scan used by the span rasterizer, against numpy."""
+    import f_renderer_amd as fr
+    r = fr.Renderer(32, 32)
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        v = rng.integers(0, 33, 64).astype(np.uint32)
+        np.testing.assert_array_equal(r.debug_scan64(v), np.cumsum(v).astype(np.uint32))
+    np.testing.assert_array_equal(r.debug_scan64(np.ones(64, np.uint32)), np.arange(1, 65, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("mode", ["sweep"])
+def test_sweep_kernel_still_exact(oracle, mode, monkeypatch):
+    """FRR_RASTER=sweep selects the brute-force tile kernel (the span kernel's fallback form)."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    monkeypatch.setenv("FRR_RASTER", mode)
+    W, H = 333, 211
+    r, f = _mk(oracle, W, H)
+    tris = scenes.random_clip_triangles(20000, W, H, seed=2, spread=1.15)
+    r.clear()
+    f.clear()
+    r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
+    f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
+    _assert_frame_equal(r, f)
