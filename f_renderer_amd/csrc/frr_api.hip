@@ -61,6 +61,7 @@ struct frr_ctx {
     int geom_vs = -1;         // VS of the last frr_geometry
     uint64_t geom_ntris = 0;
     int rank = 0, world = 1;
+    bool count_frags = true;   // exact covered-fragment statistic (disables whole-triangle early-z)
     bool raster_sweep = false; // FRR_RASTER=sweep: brute-force tile kernel instead of the span kernel
     hipEvent_t ev[16] = {};
     bool ev_set[16] = {};
@@ -192,7 +193,8 @@ template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uin
     } else {
         // the span algebra needs every coordinate it touches within +-SPAN_SAFE (no i32 wrap)
         const int win_safe = a.x0 >= -SPAN_SAFE && a.y0 >= -SPAN_SAFE && a.x1 <= SPAN_SAFE && a.y1 <= SPAN_SAFE;
-        hipLaunchKernelGGL((k_raster_span<K, PS>), dim3(grid), dim3(256), 0, c->stream, a, c->duni, win_safe);
+        if (c->count_frags) hipLaunchKernelGGL((k_raster_span<K, PS, true>), dim3(grid), dim3(256), 0, c->stream, a, c->duni, win_safe);
+        else hipLaunchKernelGGL((k_raster_span<K, PS, false>), dim3(grid), dim3(256), 0, c->stream, a, c->duni, win_safe);
     }
 }
 
@@ -291,7 +293,12 @@ int frr_set_partition(frr_ctx *c, int rank, int world)
     c->rank = rank; c->world = world;
     return FRR_OK;
 }
-int frr_set_count_fragments(frr_ctx *c, int) { return c ? FRR_OK : FRR_ERR_INVALID; } // always counted (one atomic per wave)
+int frr_set_count_fragments(frr_ctx *c, int enable)
+{
+    if (!c) return FRR_ERR_INVALID;
+    c->count_frags = enable != 0;
+    return FRR_OK;
+}
 
 int frr_bind_targets(frr_ctx *c, void *color, void *depth, void *tri_id)
 {

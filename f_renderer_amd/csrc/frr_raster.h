@@ -10,7 +10,7 @@
 //
 // Two coverage strategies produce the same fragment set {pixels passing renderer.rs:329-341}:
 //   k_raster       one triangle per wavefront, brute-force sweep of bbox-in-tile pixels (64/step);
-//   k_raster_span  64 triangles per wavefront-batch: exact per-row spans from the integer edge
+//   k_raster_span  a batch of triangles per wavefront: exact per-row spans from the integer edge
 //                  functions, then fragments packed 64 per step (no lane idles on uncovered bbox
 //                  pixels).  Triangles whose coordinates could overflow i32 in the span algebra
 //                  (|spi| > 8192, only the clipper's far-away vertices) take the brute-force sweep,
@@ -49,14 +49,17 @@ __device__ __forceinline__ TileCtx tile_ctx(const RasterArgs &a)
     return c;
 }
 
-// keys <- current depth buffer (index 0 = "what is already there")
-__device__ __forceinline__ void tile_load_keys(const RasterArgs &a, const TileCtx &c, unsigned long long *s_key)
+// keys <- current depth buffer (index 0 = "what is already there").  Pixels of a partial tile that
+// lie outside the window are never touched again; `oob` is what they hold (all-ones keeps them
+// from dragging the hierarchical-z minima down).
+__device__ __forceinline__ void tile_load_keys(const RasterArgs &a, const TileCtx &c, unsigned long long *s_key,
+                                               unsigned long long oob = 0ull)
 {
     for (int i = threadIdx.x; i < TILE_PX; i += 256) {
         const int x = i & (TILE - 1), y = i >> 5;
-        float d = 0.0f;
-        if (x < c.tw && y < c.th) d = a.depth[(size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x)];
-        s_key[i] = (unsigned long long)zkey(d) << 32;
+        unsigned long long k = oob;
+        if (x < c.tw && y < c.th) k = (unsigned long long)zkey(a.depth[(size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x)]) << 32;
+        s_key[i] = k;
     }
 }
 
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
 // k_raster_span
 // ---------------------------------------------------------------------------------------------
 constexpr int SPAN_SAFE = 8192; // |spi| and window coordinates up to this keep every edge value < 2^30
+constexpr int SPAN_BATCH = 32;  // triangles per wavefront batch (staging sized for 8 workgroups per CU)
 
 // wave64 inclusive prefix sum on the DPP network (row_shr within 16-lane rows, then row broadcasts)
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x)
@@ -191,12 +195,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x)
     return v;
 }
 
-// all LDS traffic of a wave is in order; this only stops the compiler from moving accesses across
+// A wave's LDS instructions execute in issue order, so lanes of ONE wave may exchange data through
+// LDS without waiting; this fence only keeps the compiler from reordering the accesses.
 __device__ __forceinline__ void wave_lds_fence()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
 // A 64-bit "heads" mask marks where segments start inside a window of 64 consecutive items.
@@ -212,14 +215,20 @@ __device__ __forceinline__ SegPos seg_locate(uint32_t h_lo, uint32_t h_hi, uint3
     s.off = hp >= 0 ? lane - hp : lane + carry;
     return s;
 }
+// scalar bookkeeping for the next window: heads consumed, and how far into the open segment we are
+__device__ __forceinline__ void seg_advance(uint32_t h_lo, uint32_t h_hi, int &base, int &carry)
+{
+    const int last = h_hi ? 63 - __clz((int)h_hi) : (h_lo ? 31 - __clz((int)h_lo) : -1);
+    carry = last >= 0 ? 64 - last : carry + 64;
+    base += __popc(h_lo) + __popc(h_hi);
+}
 
 struct alignas(16) TriI {     // per-triangle integers staged for the span phase
     int32_t e01, e12, e20;    // edge values at the bbox-in-tile origin
     uint32_t ab01, ab12, ab20; // A (low 16, signed) | B (high 16, signed)
     uint32_t misc;            // bx0l:5 | by0l:5 <<5 | bw:6 <<10 | bias bits <<16
-    uint32_t id;              // triangle index + 1
+    uint32_t zub;             // zkey of an upper bound of rhw over the triangle
 };
-struct alignas(16) TriF { float s0x, s0y, s1x, s1y, s2x, s2y, r0, r1, r2, pad0, pad1, pad2; };
 
 // dx in [lo,hi) with  Er + A*dx > thr  (thr in {-1,0}); exact floor division, see DESIGN.md
 __device__ __forceinline__ void edge_bound(int Er, int A, int thr, int &lo, int &hi)
@@ -236,19 +245,44 @@ __device__ __forceinline__ void edge_bound(int Er, int A, int thr, int &lo, int 
     if (A > 0) lo = max(lo, q); else hi = min(hi, q + 1);
 }
 
-template <int K, int PS>
+// Hierarchical z: s_hiz[row*4 + seg] = min over the 8 pixels of (row, seg) of the depth part of the
+// current keys, s_hiz8[by*4 + seg] = min over the 8x8 block.  Depth keys only grow, so a value read
+// late, or written by another wave a moment ago, is still a valid lower bound: no synchronisation.
+// One wave rebuilds all 128 + 16 entries (lane L: segments L and L+64, 64 contiguous bytes each).
+__device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uint32_t *s_hiz, uint32_t *s_hiz8, int lane)
+{
+    uint32_t m[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(s_key + (size_t)(lane + 64 * k) * 8);
+        const uint4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+        m[k] = min(min(min(a0.y, a0.w), min(a1.y, a1.w)), min(min(a2.y, a2.w), min(a3.y, a3.w)));
+        s_hiz[lane + 64 * k] = m[k];
+        uint32_t b = m[k];
+        b = min(b, (uint32_t)__shfl_xor((int)b, 4));
+        b = min(b, (uint32_t)__shfl_xor((int)b, 8));
+        b = min(b, (uint32_t)__shfl_xor((int)b, 16));
+        if ((lane & 28) == 0) s_hiz8[(2 * k + (lane >> 5)) * 4 + (lane & 3)] = b;
+    }
+}
+
+template <int K, int PS, bool COUNT>
 __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u, int win_safe)
 {
+    constexpr int B = SPAN_BATCH;
     __shared__ unsigned long long s_key[TILE_PX];
-    __shared__ TriI s_ti[4][64];
-    __shared__ TriF s_tf[4][64];
-    __shared__ uint32_t s_hrow[4][64];  // heads of (triangle -> rows)
-    __shared__ uint32_t s_hfrag[4][64]; // heads of (span -> fragments)
-    __shared__ uint32_t s_q[4][64];     // compacted span descriptors
+    __shared__ TriI s_ti[4][B];
+    __shared__ float4 s_fa[4][B];                  // s0x s0y s1x s1y
+    __shared__ float4 s_fb[4][B];                  // s2x s2y rhw0 rhw1
+    __shared__ float2 s_fc[4][B];                  // rhw2, bit pattern of (triangle index + 1)
+    __shared__ unsigned long long s_hrow[4][B / 2]; // heads of (triangle -> rows): B*32 bits
+    __shared__ unsigned long long s_hfrag[4][32];  // heads of (span -> fragments): 64*32 bits
+    __shared__ uint32_t s_q[4][64];                // compacted span descriptors
+    __shared__ uint32_t s_hiz[128], s_hiz8[16];    // hierarchical z (see hiz_rebuild)
     __shared__ uint32_t s_next;
     const TileCtx c = tile_ctx(a);
     if (c.beg >= c.end) return;
-    tile_load_keys(a, c, s_key);
+    tile_load_keys(a, c, s_key, ~0ull);
     if (threadIdx.x == 0) s_next = 0;
     __syncthreads();
 
@@ -262,15 +296,18 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(&s_next, 1u);
         b = __builtin_amdgcn_readfirstlane(b);
-        const uint32_t e0 = c.beg + b * 64u;
+        const uint32_t e0 = c.beg + b * (uint32_t)B;
         if (e0 >= c.end) break;
-        const int nb = (int)min(64u, c.end - e0);
+        const int nb = (int)min((uint32_t)B, c.end - e0);
+        hiz_rebuild(s_key, s_hiz, s_hiz8, lane);
+        wave_lds_fence();
 
         // ---- phase 1: lane = triangle.  Record -> bbox-in-tile, edge coefficients, staging ----
         const bool valid = lane < nb;
         const uint32_t t = valid ? a.bins[e0 + lane] : 0u;
         const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + t);
-        const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+        if (valid) { q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3]; }
         const int p0x = (int)q0.x, p0y = (int)q0.y, p1x = (int)q0.z, p1y = (int)q0.w, p2x = (int)q1.x, p2y = (int)q1.y;
         int bx0 = clampi(min(p0x, min(p1x, p2x)), a.x0, a.x1), bx1 = clampi(max(p0x, max(p1x, p2x)), a.x0, a.x1);
         int by0 = clampi(min(p0y, min(p1y, p2y)), a.y0, a.y1), by1 = clampi(max(p0y, max(p1y, p2y)), a.y0, a.y1);
@@ -281,9 +318,23 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
         const bool nonempty = valid && bw > 0 && bh > 0;
         const bool safe = nonempty && win_safe && amax <= SPAN_SAFE;
         const unsigned long long unsafe_mask = __ballot(nonempty && !safe);
-        const uint32_t rows = safe ? (uint32_t)bh : 0u;
-        {
-            // wrapping arithmetic (values are only meaningful, and only used, for `safe` triangles)
+        // Upper bound on any fragment's rhw: rhw = (r0*a + r1*b) + r2*c with a+b+c = 1 up to a few
+        // roundings, so |rhw| <= max|r_i| * (1 + 2^-18).  NaN vertices disable the bound.
+        const float ar0 = fabsf(u2f(q3.x)), ar1 = fabsf(u2f(q3.y)), ar2 = fabsf(u2f(q3.z));
+        const float ub = fmaxf(fmaxf(ar0, ar1), ar2) * 1.000003814697265625f;
+        const uint32_t zub = (ar0 == ar0 && ar1 == ar1 && ar2 == ar2) ? zkey(ub) : 0xFFFFFFFFu;
+        bool alive = safe;
+        if (!COUNT && safe) {
+            // whole-triangle early-z against the 8x8 block minima (when the bbox touches <= 2x2 blocks)
+            const int gx0 = (bx0 - c.ax0) >> 3, gx1 = (bx1 - 1 - c.ax0) >> 3, gy0 = (by0 - c.ay0) >> 3, gy1 = (by1 - 1 - c.ay0) >> 3;
+            if (gx1 - gx0 <= 1 && gy1 - gy0 <= 1) {
+                const uint32_t hm = min(min(s_hiz8[gy0 * 4 + gx0], s_hiz8[gy0 * 4 + gx1]), min(s_hiz8[gy1 * 4 + gx0], s_hiz8[gy1 * 4 + gx1]));
+                alive = !(zub < hm);
+            }
+        }
+        const uint32_t rows = alive ? (uint32_t)bh : 0u;
+        if (alive) {
+            // wrapping arithmetic spelled in u32; for `safe` triangles nothing wraps
             const uint32_t A01 = 0u - (uint32_t)(p1y - p0y), B01 = (uint32_t)(p1x - p0x);
             const uint32_t A12 = 0u - (uint32_t)(p2y - p1y), B12 = (uint32_t)(p2x - p1x);
             const uint32_t A20 = 0u - (uint32_t)(p0y - p2y), B20 = (uint32_t)(p0x - p2x);
@@ -295,39 +346,41 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
             ti.ab12 = (A12 & 0xFFFFu) | (B12 << 16);
             ti.ab20 = (A20 & 0xFFFFu) | (B20 << 16);
             ti.misc = (uint32_t)(bx0 - c.ax0) | ((uint32_t)(by0 - c.ay0) << 5) | ((uint32_t)bw << 10) | (((q3.w >> 1) & 7u) << 16);
-            ti.id = t + 1u;
-            if (safe) s_ti[w][lane] = ti;
-            TriF tf;
-            tf.s0x = u2f(q1.z); tf.s0y = u2f(q1.w); tf.s1x = u2f(q2.x); tf.s1y = u2f(q2.y);
-            tf.s2x = u2f(q2.z); tf.s2y = u2f(q2.w); tf.r0 = u2f(q3.x); tf.r1 = u2f(q3.y); tf.r2 = u2f(q3.z);
-            tf.pad0 = tf.pad1 = tf.pad2 = 0.0f;
-            if (safe) s_tf[w][lane] = tf;
+            ti.zub = zub;
+            s_ti[w][lane] = ti;
+            s_fa[w][lane] = make_float4(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y));
+            s_fb[w][lane] = make_float4(u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y));
+            s_fc[w][lane] = make_float2(u2f(q3.z), u2f(t + 1u));
         }
         // rows of all triangles laid end to end: heads mark where each triangle's rows start
         const uint32_t rincl = wave_incl_scan_dpp(rows);
         const int R = (int)__builtin_amdgcn_readlane((int)rincl, 63);
-        s_hrow[w][lane] = 0u;
+        if (lane < B / 2) s_hrow[w][lane] = 0ull;
         wave_lds_fence();
-        if (rows) { const uint32_t st = rincl - rows; atomicOr(&s_hrow[w][st >> 5], 1u << (st & 31)); }
-        wave_lds_fence();
-        // compact index of each safe triangle (heads are counted, so triangles are addressed by rank)
+        if (rows) {
+            const uint32_t st = rincl - rows;
+            atomicOr(reinterpret_cast<uint32_t *>(&s_hrow[w][0]) + (st >> 5), 1u << (st & 31));
+        }
+        // heads are counted, so triangles are addressed by rank among the safe ones: rank -> lane
         const unsigned long long safe_mask = __ballot(rows != 0u);
         const int trank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(safe_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)safe_mask, 0u));
-        if (rows) s_q[w][trank] = (uint32_t)lane; // rank -> lane (reuses s_q before the span phase needs it)
+        if (rows) s_q[w][trank] = (uint32_t)lane;
         wave_lds_fence();
-        uint32_t tri_of_rank = s_q[w][lane];      // lane L holds the lane index of the L-th safe triangle
+        const uint32_t tri_of_rank = s_q[w][lane & (B - 1)];
         wave_lds_fence();
 
         int jbase = 0, jcarry = 0; // heads seen in earlier row windows; rows of the open triangle already done
         for (int r0 = 0; r0 < R; r0 += 64) {
             // ---- phase 2: lane = (triangle, row).  Exact covered span of that row. ----
-            const uint32_t h_lo = __builtin_amdgcn_readfirstlane(s_hrow[w][r0 >> 5]);
-            const uint32_t h_hi = __builtin_amdgcn_readfirstlane(s_hrow[w][(r0 >> 5) + 1 < 64 ? (r0 >> 5) + 1 : 63]) & ((r0 >> 5) + 1 < 64 ? ~0u : 0u);
+            const unsigned long long hrow = s_hrow[w][r0 >> 6];
+            const uint32_t h_lo = __builtin_amdgcn_readfirstlane((uint32_t)hrow);
+            const uint32_t h_hi = __builtin_amdgcn_readfirstlane((uint32_t)(hrow >> 32));
             const SegPos sp = seg_locate(h_lo, h_hi, le_lo, le_hi, lane, jcarry);
             const bool ractive = r0 + lane < R;
             const int jr = jbase + sp.k - 1;                                   // rank of the triangle
             const int j = __shfl((int)tri_of_rank, ractive ? jr : 0);          // its staging slot (lane of phase 1)
             int len = 0, xl = 0, yl = 0;
+            uint32_t zu = 0xFFFFFFFFu;
             if (ractive) {
                 const TriI ti = s_ti[w][j];
                 const int row = sp.off;
@@ -342,13 +395,14 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
                 len = max(hi - lo, 0);
                 xl = (int)(ti.misc & 31u) + lo;
                 yl = (int)((ti.misc >> 5) & 31u) + row;
+                zu = ti.zub;
             }
-            // next window's carry-in for the row heads
-            {
-                const int nh = __popc(h_lo) + __popc(h_hi);
-                const int last = h_hi ? 63 - __clz((int)h_hi) : (h_lo ? 31 - __clz((int)h_lo) : -1);
-                jcarry = last >= 0 ? 64 - last : jcarry + 64;
-                jbase += nh;
+            seg_advance(h_lo, h_hi, jbase, jcarry);
+            if (COUNT) n_cov += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp((uint32_t)len), 63);
+            // span-level early-z against the (row, 8-px segment) minima
+            if (len > 0) {
+                const int g0 = xl >> 3, g1 = (xl + len - 1) >> 3;
+                if (g1 - g0 <= 1 && zu < min(s_hiz[yl * 4 + g0], s_hiz[yl * 4 + g1])) len = 0;
             }
             // ---- spans of this window laid end to end: heads mark where each span's fragments start ----
             const unsigned long long nz = __ballot(len > 0);
@@ -356,38 +410,35 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
             const int srank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
             const uint32_t fincl = wave_incl_scan_dpp((uint32_t)len);
             const int F = (int)__builtin_amdgcn_readlane((int)fincl, 63);
-            s_hfrag[w][lane] = 0u;
+            if (lane < 32) s_hfrag[w][lane] = 0ull;
             wave_lds_fence();
             if (len > 0) {
                 const uint32_t st = fincl - (uint32_t)len;
-                atomicOr(&s_hfrag[w][st >> 5], 1u << (st & 31));
+                atomicOr(reinterpret_cast<uint32_t *>(&s_hfrag[w][0]) + (st >> 5), 1u << (st & 31));
                 s_q[w][srank] = (uint32_t)j | ((uint32_t)yl << 6) | ((uint32_t)xl << 11); // span descriptor
             }
             wave_lds_fence();
-            n_cov += (uint32_t)F;
 
             // ---- phase 3: lane = fragment.  Barycentrics, rhw, z key, LDS atomic max ----
             int qbase = 0, qcarry = 0;
             for (int f0 = 0; f0 < F; f0 += 64) {
-                const uint32_t g_lo = __builtin_amdgcn_readfirstlane(s_hfrag[w][f0 >> 5]);
-                const uint32_t g_hi = __builtin_amdgcn_readfirstlane(s_hfrag[w][(f0 >> 5) + 1 < 64 ? (f0 >> 5) + 1 : 63]) & ((f0 >> 5) + 1 < 64 ? ~0u : 0u);
+                const unsigned long long hf = s_hfrag[w][f0 >> 6];
+                const uint32_t g_lo = __builtin_amdgcn_readfirstlane((uint32_t)hf);
+                const uint32_t g_hi = __builtin_amdgcn_readfirstlane((uint32_t)(hf >> 32));
                 const SegPos fp = seg_locate(g_lo, g_hi, le_lo, le_hi, lane, qcarry);
                 if (f0 + lane < F) {
                     const uint32_t d = s_q[w][qbase + fp.k - 1];
                     const int sj = (int)(d & 63u), y = (int)((d >> 6) & 31u), x = (int)((d >> 11) & 31u) + fp.off;
-                    const TriF tf = s_tf[w][sj];
-                    const uint32_t id = s_ti[w][sj].id;
-                    Frag f = frag_eval(tf.s0x, tf.s0y, tf.s1x, tf.s1y, tf.s2x, tf.s2y, tf.r0, tf.r1, tf.r2, c.ax0 + x, c.ay0 + y);
+                    const float4 fa = s_fa[w][sj], fb = s_fb[w][sj];
+                    const float2 fc = s_fc[w][sj];
+                    Frag f = frag_eval(fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w, fc.x, c.ax0 + x, c.ay0 + y);
                     if (f.valid) {
                         if (f.rhw != f.rhw) ++n_nan;
-                        const unsigned long long key = ((unsigned long long)zkey(f.rhw) << 32) | (unsigned long long)id;
+                        const unsigned long long key = ((unsigned long long)zkey(f.rhw) << 32) | (unsigned long long)f2u(fc.y);
                         atomicMax(&s_key[y * TILE + x], key);
                     }
                 }
-                const int nh = __popc(g_lo) + __popc(g_hi);
-                const int last = g_hi ? 63 - __clz((int)g_hi) : (g_lo ? 31 - __clz((int)g_lo) : -1);
-                qcarry = last >= 0 ? 64 - last : qcarry + 64;
-                qbase += nh;
+                seg_advance(g_lo, g_hi, qbase, qcarry);
             }
             wave_lds_fence(); // s_q / s_hfrag are rewritten by the next row window
         }

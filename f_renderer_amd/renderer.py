@@ -195,6 +195,9 @@ class Renderer:
     def set_partition(self, rank, world):
         self._check(self._lib.frr_set_partition(self._ctx, rank, world))
 
+    def set_count_fragments(self, enable):
+        self._check(self._lib.frr_set_count_fragments(self._ctx, 1 if enable else 0))
+
     def bind_targets(self, color_ptr=None, depth_ptr=None, tri_id_ptr=None):
         self._check(self._lib.frr_bind_targets(self._ctx, C.c_void_p(color_ptr or 0), C.c_void_p(depth_ptr or 0),
                                                C.c_void_p(tri_id_ptr or 0)))

@@ -87,7 +87,7 @@ typedef struct frr_stats {
     uint64_t tris_in;      /* input triangles submitted since the last frr_clear */
     uint64_t tris_setup;   /* triangles after clip + fan */
     uint64_t bin_entries;  /* (triangle, tile) pairs */
-    uint64_t frag_covered; /* pass the edge tests renderer.rs:333-341 (only if counting enabled) */
+    uint64_t frag_covered; /* pass the edge tests renderer.rs:333-341 (exact only while counting is enabled) */
     uint64_t frag_nan;     /* NaN rhw fragments (unsupported: sticky in the reference) */
     uint32_t draws;
     uint32_t overflow;     /* non-zero => this frame is invalid, see FRR_ERR_CAPACITY */
@@ -106,7 +106,9 @@ int frr_abi_version(void);
 /* Screen-tile partition for multi-GPU runs: this ctx rasterizes only tile rows ty with
  * ty % world == rank (geometry is replicated).  Default (0,1) = everything. */
 int frr_set_partition(frr_ctx *ctx, int rank, int world);
-/* Counting covered fragments costs one atomic per wave iteration; off by default. */
+/* frr_stats.frag_covered is exact while counting is enabled (default).  Disabling it lets the tile
+ * kernel drop whole triangles by hierarchical early-z before their coverage is known (images are
+ * identical either way; only the statistic stops being maintained). */
 int frr_set_count_fragments(frr_ctx *ctx, int enable);
 
 /* Use caller-owned DEVICE buffers (e.g. torch tensors) as the frame targets instead of the

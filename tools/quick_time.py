@@ -13,13 +13,15 @@ m = r.upload_mesh(tris, fr.VS_CLIP)
 for _ in range(3):
     r.clear(); r.draw(m, fr.PS_DEPTH)
 r.sync()
+st_count = r.stats()
+r.set_count_fragments(os.environ.get('COUNT','0')=='1')
 K = 10
 r.event_record(0)
 for _ in range(K):
     r.clear(); r.draw(m, fr.PS_DEPTH)
 r.event_record(1)
 ms = r.event_elapsed_ms(0, 1) / K
-st = r.stats()
+st = st_count
 print(f"{W}x{H} n={n}: frame {ms:.3f} ms  -> {n/ms/1e3:.1f} Mtri/s, {st['frag_covered']/ms/1e3:.1f} Mfrag/s", st)
 r.profile_enable(True); r.profile_reset()
 for _ in range(K):
