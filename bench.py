@@ -144,11 +144,19 @@ def main():
                 if rank == 0:
                     final.view(rows_per_rank, world, 32, W).copy_(gbuf.permute(1, 0, 2, 3))
 
+        # one counted frame: the exact covered-fragment count of this rank's tiles (the Mfrag/s
+        # numerator).  The statistic is then switched off: maintaining it forbids the tile kernel's
+        # whole-triangle early-z (outputs are identical either way, tests/test_gpu_earlyz.py).
+        r.set_count_fragments(True)
+        step()
+        r.sync()
+        counted = r.stats()
+        r.set_count_fragments(False)
         for _ in range(args.warmup):
             step()
         r.sync()
         stats = r.stats()
-        if stats["overflow"]:
+        if stats["overflow"] or counted["overflow"]:
             raise SystemExit("device work list overflow during warmup")
 
         r.profile_reset()
@@ -174,7 +182,7 @@ def main():
             image_ok = bool(torch.isfinite(final[:H]).all().item())
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    cov = torch.tensor([float(stats["frag_covered"])], dtype=torch.float64, device="cuda")
+    cov = torch.tensor([float(counted["frag_covered"])], dtype=torch.float64, device="cuda")
     if dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cov, op=dist.ReduceOp.SUM)

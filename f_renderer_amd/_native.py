@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libfrr_hip.so")
+LIB_PATH = os.environ.get("FRR_LIB") or os.path.join(_HERE, "libfrr_hip.so")  # FRR_LIB: developer override
 _SRC = [os.path.join(_HERE, "csrc", f) for f in ("frr_api.hip", "frr_kernels.h", "frr_raster.h", "frr_device.h", "frr_exact.h")]
 _HDR = os.path.join(_ROOT, "include", "frr.h")
 
@@ -123,7 +123,7 @@ def lib():
     """Load libfrr_hip.so; raises (loudly) if it is missing and cannot be built."""
     global _lib
     if _lib is None:
-        if needs_build():
+        if not os.environ.get("FRR_LIB") and needs_build():
             build()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():

@@ -52,6 +52,7 @@ struct frr_ctx {
     uint32_t *tile_counts = nullptr, *tile_offsets = nullptr, *tile_cursor = nullptr;
     uint32_t max_tiles = 0;
     uint32_t *bins = nullptr; size_t bin_cap = 0;
+    uint32_t *bins2 = nullptr; size_t bin2_cap = 0; // per-tile near-first reordering written by the tile kernel
     uint32_t *bin_matrix = nullptr; size_t bin_matrix_cap = 0; // [G][ntiles] per-chunk tile histograms
     bool lds_attr_set = false;
     std::vector<Mesh> meshes;
@@ -168,6 +169,7 @@ int check_frame_counters(frr_ctx *c, Counters *host)
         if (h.overflow & 2u) {
             size_t need = (size_t)(h.bin_total + h.bin_total / 4 + 1024);
             if (ensure(c, c->bins, c->bin_cap, need) != FRR_OK) return FRR_ERR_NOMEM;
+            if (ensure(c, c->bins2, c->bin2_cap, need) != FRR_OK) return FRR_ERR_NOMEM;
         }
         if (h.overflow & 1u) c->setup_hint = (size_t)h.need_setup + h.need_setup / 8 + 1024;
         return fail(c, FRR_ERR_CAPACITY, "device work list overflowed; capacity grown, re-issue the frame");
@@ -279,7 +281,7 @@ void frr_destroy(frr_ctx *c)
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
     void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->clip_list, c->recs, c->vary,
-                    c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bin_matrix};
+                    c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bins2, c->bin_matrix};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -471,7 +473,9 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     if (!c->bins) {
         size_t want = std::max<size_t>((size_t)c->geom_ntris * 8 + 4 * (size_t)c->max_tiles, (size_t)1 << 22);
         if ((rc = ensure(c, c->bins, c->bin_cap, want)) != FRR_OK) return rc;
+        if ((rc = ensure(c, c->bins2, c->bin2_cap, want)) != FRR_OK) return rc;
     }
+    a.bins2 = c->bins2;
     a.bins = c->bins; a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xFFFFFFFFu);
     a.color = c->color; a.depth = c->depth; a.tri_id = c->tri_id; a.cnt = c->cnt;
     if (ntiles <= BIN_LDS_MAX_TILES) {
@@ -577,6 +581,11 @@ int frr_get_stats(frr_ctx *c, frr_stats *out)
     out->frag_nan = h.frag_nan;
     out->draws = h.draws;
     out->overflow = h.overflow;
+    if (getenv("FRR_DEBUG_PRINT")) {
+        fprintf(stderr, "frr dbg:");
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %llu", h.dbg[k]);
+        fprintf(stderr, "\n");
+    }
     return FRR_OK;
 }
 

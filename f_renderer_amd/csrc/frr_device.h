@@ -36,6 +36,7 @@ struct Counters {
     uint64_t bin_entries_frame;
     uint32_t draws;
     uint32_t need_setup;    // setup triangles the current draw needs (valid even on overflow)
+    unsigned long long dbg[8]; // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py)
 };
 
 struct DevUniforms {
@@ -75,6 +76,7 @@ struct RasterArgs {
     uint32_t *tile_offsets;           // [ntiles+1]
     uint32_t *tile_cursor;            // [ntiles]
     uint32_t *bins;
+    uint32_t *bins2;                  // same capacity; scratch for the tile kernel's near-first order
     uint32_t bin_cap;
     uint8_t *color;
     float *depth;

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void k_clear(uint4 *__restrict__ color, uint4 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cnt->n_setup = 0; cnt->n_clip = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
         cnt->frag_covered = 0; cnt->frag_nan = 0; cnt->tris_in = 0; cnt->bin_entries_frame = 0; cnt->draws = 0;
+        for (int k = 0; k < 8; ++k) cnt->dbg[k] = 0;
     }
 }
 // tail elements when W*H is not a multiple of 4

@@ -248,21 +248,38 @@ __device__ __forceinline__ void edge_bound(int Er, int A, int thr, int &lo, int 
 // Hierarchical z: s_hiz[row*4 + seg] = min over the 8 pixels of (row, seg) of the depth part of the
 // current keys, s_hiz8[by*4 + seg] = min over the 8x8 block.  Depth keys only grow, so a value read
 // late, or written by another wave a moment ago, is still a valid lower bound: no synchronisation.
-// One wave rebuilds all 128 + 16 entries (lane L: segments L and L+64, 64 contiguous bytes each).
-__device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uint32_t *s_hiz, uint32_t *s_hiz8, int lane)
+// Layout of the array hz[HZ_SIZE]: [HZ_SEG + row*4 + seg] 8-pixel row segments, [HZ_BLK + by*4 + bx]
+// 8x8 blocks, [HZ_QUAD + qy*2 + qx] 16x16 quads, [HZ_ROW + row] whole tile rows.
+constexpr int HZ_SEG = 0, HZ_BLK = 128, HZ_QUAD = 144, HZ_ROW = 148, HZ_SIZE = 180;
+__device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uint32_t *hz, int lane)
 {
-    uint32_t m[2];
+    // consecutive lanes read consecutive 16-byte chunks (2 keys): conflict-free; 4 lanes = one segment
+    const uint4 *p = reinterpret_cast<const uint4 *>(s_key);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(s_key + (size_t)(lane + 64 * k) * 8);
-        const uint4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
-        m[k] = min(min(min(a0.y, a0.w), min(a1.y, a1.w)), min(min(a2.y, a2.w), min(a3.y, a3.w)));
-        s_hiz[lane + 64 * k] = m[k];
-        uint32_t b = m[k];
-        b = min(b, (uint32_t)__shfl_xor((int)b, 4));
-        b = min(b, (uint32_t)__shfl_xor((int)b, 8));
-        b = min(b, (uint32_t)__shfl_xor((int)b, 16));
-        if ((lane & 28) == 0) s_hiz8[(2 * k + (lane >> 5)) * 4 + (lane & 3)] = b;
+    for (int k = 0; k < 8; ++k) {
+        const uint4 v = p[64 * k + lane];
+        uint32_t m = min(v.y, v.w);
+        m = min(m, (uint32_t)__shfl_xor((int)m, 1));
+        m = min(m, (uint32_t)__shfl_xor((int)m, 2));
+        if ((lane & 3) == 0) hz[HZ_SEG + 16 * k + (lane >> 2)] = m;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < 16) {                       // 8x8 blocks: 8 rows of one segment column
+        const int by = lane >> 2, bx = lane & 3;
+        uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) m = min(m, hz[HZ_SEG + (by * 8 + r) * 4 + bx]);
+        hz[HZ_BLK + lane] = m;
+    } else if (lane < 48) {                // whole rows: 4 segments
+        const int row = lane - 16;
+        const uint4 v = *reinterpret_cast<const uint4 *>(&hz[HZ_SEG + row * 4]);
+        hz[HZ_ROW + row] = min(min(v.x, v.y), min(v.z, v.w));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < 4) {                        // 16x16 quads: 2x2 blocks
+        const int qy = lane >> 1, qx = lane & 1;
+        const uint32_t *b = hz + HZ_BLK + (qy * 2) * 4 + qx * 2;
+        hz[HZ_QUAD + lane] = min(min(b[0], b[1]), min(b[4], b[5]));
     }
 }
 
@@ -278,19 +295,65 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
     __shared__ unsigned long long s_hrow[4][B / 2]; // heads of (triangle -> rows): B*32 bits
     __shared__ unsigned long long s_hfrag[4][32];  // heads of (span -> fragments): 64*32 bits
     __shared__ uint32_t s_q[4][64];                // compacted span descriptors
-    __shared__ uint32_t s_hiz[128], s_hiz8[16];    // hierarchical z (see hiz_rebuild)
+    __shared__ __attribute__((aligned(16))) uint32_t s_hz[HZ_SIZE]; // hierarchical z (see hiz_rebuild)
     __shared__ uint32_t s_next;
+    __shared__ uint32_t s_bkt[64];
     const TileCtx c = tile_ctx(a);
     if (c.beg >= c.end) return;
     tile_load_keys(a, c, s_key, ~0ull);
     if (threadIdx.x == 0) s_next = 0;
+    if (threadIdx.x < 64) s_bkt[threadIdx.x] = 0;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // ---- near-first order: a coarse bucket sort of this tile's bin by the triangles' depth upper
+    // bound (64 buckets: 4 exponent bits + 2 mantissa bits of max|rhw_i|).  Processing order does not
+    // change any output (the z resolution is order independent); it only makes early-z reject more.
+    const uint32_t *__restrict__ bin_order = a.bins;
+    if (!COUNT && c.end - c.beg > 2u * B) {
+        uint32_t ct[4], cb[4];
+        auto bucket_of = [&](uint32_t t) {
+            const uint4 q3 = reinterpret_cast<const uint4 *>(a.recs + t)[3];
+            const float m = fmaxf(fmaxf(fabsf(u2f(q3.x)), fabsf(u2f(q3.y))), fabsf(u2f(q3.z)));
+            return 63u - ((f2u(m) >> 21) & 63u);
+        };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = c.beg + threadIdx.x + 256u * k;
+            ct[k] = 0; cb[k] = 0;
+            if (e < c.end) { ct[k] = a.bins[e]; cb[k] = bucket_of(ct[k]); atomicAdd(&s_bkt[cb[k]], 1u); }
+        }
+        for (uint32_t e = c.beg + threadIdx.x + 1024u; e < c.end; e += 256u) atomicAdd(&s_bkt[bucket_of(a.bins[e])], 1u);
+        __syncthreads();
+        if (w == 0) {
+            const uint32_t x = s_bkt[lane];
+            const uint32_t incl = wave_incl_scan_dpp(x);
+            s_bkt[lane] = c.beg + incl - x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = c.beg + threadIdx.x + 256u * k;
+            if (e < c.end) a.bins2[atomicAdd(&s_bkt[cb[k]], 1u)] = ct[k];
+        }
+        for (uint32_t e = c.beg + threadIdx.x + 1024u; e < c.end; e += 256u) {
+            const uint32_t t = a.bins[e];
+            a.bins2[atomicAdd(&s_bkt[bucket_of(t)], 1u)] = t;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        bin_order = a.bins2;
+    }
+
     const uint32_t le_lo = lane < 32 ? (2u << lane) - 1u : 0xFFFFFFFFu;
     const uint32_t le_hi = lane < 32 ? 0u : (2u << (lane - 32)) - 1u;
     uint32_t n_cov = 0, n_nan = 0;
+#ifdef FRR_DEBUG_COUNTERS
+    uint32_t d_tri = 0, d_alive = 0, d_rows = 0, d_spans = 0, d_spans_live = 0, d_frags = 0, d_fwin = 0, d_rwin = 0;
+#endif
 
     for (;;) {
         uint32_t b = 0;
@@ -299,12 +362,12 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
         const uint32_t e0 = c.beg + b * (uint32_t)B;
         if (e0 >= c.end) break;
         const int nb = (int)min((uint32_t)B, c.end - e0);
-        hiz_rebuild(s_key, s_hiz, s_hiz8, lane);
+        hiz_rebuild(s_key, s_hz, lane);
         wave_lds_fence();
 
         // ---- phase 1: lane = triangle.  Record -> bbox-in-tile, edge coefficients, staging ----
         const bool valid = lane < nb;
-        const uint32_t t = valid ? a.bins[e0 + lane] : 0u;
+        const uint32_t t = valid ? bin_order[e0 + lane] : 0u;
         const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + t);
         uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
         if (valid) { q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3]; }
@@ -325,14 +388,20 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
         const uint32_t zub = (ar0 == ar0 && ar1 == ar1 && ar2 == ar2) ? zkey(ub) : 0xFFFFFFFFu;
         bool alive = safe;
         if (!COUNT && safe) {
-            // whole-triangle early-z against the 8x8 block minima (when the bbox touches <= 2x2 blocks)
+            // whole-triangle early-z: against the 8x8 block minima when the bbox touches <= 2x2 blocks,
+            // else against the 16x16 quad minima (a tile has 2x2 quads, so this always applies)
             const int gx0 = (bx0 - c.ax0) >> 3, gx1 = (bx1 - 1 - c.ax0) >> 3, gy0 = (by0 - c.ay0) >> 3, gy1 = (by1 - 1 - c.ay0) >> 3;
-            if (gx1 - gx0 <= 1 && gy1 - gy0 <= 1) {
-                const uint32_t hm = min(min(s_hiz8[gy0 * 4 + gx0], s_hiz8[gy0 * 4 + gx1]), min(s_hiz8[gy1 * 4 + gx0], s_hiz8[gy1 * 4 + gx1]));
-                alive = !(zub < hm);
-            }
+            const bool small = gx1 - gx0 <= 1 && gy1 - gy0 <= 1;
+            const uint32_t *lv = s_hz + (small ? HZ_BLK : HZ_QUAD);
+            const int sh = small ? 0 : 1, st = small ? 4 : 2;
+            const int ix0 = gx0 >> sh, ix1 = gx1 >> sh, iy0 = gy0 >> sh, iy1 = gy1 >> sh;
+            const uint32_t hm = min(min(lv[iy0 * st + ix0], lv[iy0 * st + ix1]), min(lv[iy1 * st + ix0], lv[iy1 * st + ix1]));
+            alive = !(zub < hm);
         }
         const uint32_t rows = alive ? (uint32_t)bh : 0u;
+#ifdef FRR_DEBUG_COUNTERS
+        d_tri += __popcll(__ballot(nonempty)); d_alive += __popcll(__ballot(alive));
+#endif
         if (alive) {
             // wrapping arithmetic spelled in u32; for `safe` triangles nothing wraps
             const uint32_t A01 = 0u - (uint32_t)(p1y - p0y), B01 = (uint32_t)(p1x - p0x);
@@ -397,15 +466,22 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
                 yl = (int)((ti.misc >> 5) & 31u) + row;
                 zu = ti.zub;
             }
+#ifdef FRR_DEBUG_COUNTERS
+            d_rwin++; d_rows += __popcll(__ballot(ractive)); d_spans += __popcll(__ballot(len > 0));
+#endif
             seg_advance(h_lo, h_hi, jbase, jcarry);
             if (COUNT) n_cov += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp((uint32_t)len), 63);
             // span-level early-z against the (row, 8-px segment) minima
             if (len > 0) {
                 const int g0 = xl >> 3, g1 = (xl + len - 1) >> 3;
-                if (g1 - g0 <= 1 && zu < min(s_hiz[yl * 4 + g0], s_hiz[yl * 4 + g1])) len = 0;
+                const uint32_t hm = g1 - g0 <= 1 ? min(s_hz[HZ_SEG + yl * 4 + g0], s_hz[HZ_SEG + yl * 4 + g1]) : s_hz[HZ_ROW + yl];
+                if (zu < hm) len = 0;
             }
             // ---- spans of this window laid end to end: heads mark where each span's fragments start ----
             const unsigned long long nz = __ballot(len > 0);
+#ifdef FRR_DEBUG_COUNTERS
+            d_spans_live += __popcll(nz);
+#endif
             if (nz == 0ull) continue;
             const int srank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
             const uint32_t fincl = wave_incl_scan_dpp((uint32_t)len);
@@ -420,6 +496,9 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
             wave_lds_fence();
 
             // ---- phase 3: lane = fragment.  Barycentrics, rhw, z key, LDS atomic max ----
+#ifdef FRR_DEBUG_COUNTERS
+            d_frags += F; d_fwin += (F + 63) / 64;
+#endif
             int qbase = 0, qcarry = 0;
             for (int f0 = 0; f0 < F; f0 += 64) {
                 const unsigned long long hf = s_hfrag[w][f0 >> 6];
@@ -456,6 +535,14 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
         wave_lds_fence(); // staging is rewritten by the next batch
     }
     if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
+#ifdef FRR_DEBUG_COUNTERS
+    if (lane == 0) {
+        unsigned long long *d = a.cnt->dbg;
+        atomicAdd(d + 0, (unsigned long long)d_tri); atomicAdd(d + 1, (unsigned long long)d_alive); atomicAdd(d + 2, (unsigned long long)d_rows);
+        atomicAdd(d + 3, (unsigned long long)d_spans); atomicAdd(d + 4, (unsigned long long)d_spans_live); atomicAdd(d + 5, (unsigned long long)d_frags);
+        atomicAdd(d + 6, (unsigned long long)d_fwin); atomicAdd(d + 7, (unsigned long long)d_rwin);
+    }
+#endif
     if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
     __syncthreads();
     tile_resolve<K, PS>(a, u, c, s_key);
