@@ -45,9 +45,13 @@ struct frr_ctx {
     Counters *cnt = nullptr;
     // geometry workspace
     uint32_t *block_sums = nullptr; size_t block_sums_cap = 0;
+    unsigned long long *lb_status = nullptr; size_t lb_status_cap = 0;
+    int bin_g = 0;             // FRR_BIN_G: override the number of binning chunks (dev)
+    bool geom_twopass = true;  // default; FRR_GEOM=lookback selects the single-pass look-back kernel (slower on MI355X: 79 vs 57 us at 1M tris)
     uint2 *clip_list = nullptr; size_t clip_cap = 0;
     RasterRec *recs = nullptr; size_t setup_cap = 0; size_t setup_hint = 0;
     float *vary = nullptr; size_t vary_cap = 0; // floats
+    uint2 *pbox = nullptr; size_t pbox_cap = 0;
     // binning workspace
     uint32_t *tile_counts = nullptr, *tile_offsets = nullptr, *tile_cursor = nullptr;
     uint32_t max_tiles = 0;
@@ -179,11 +183,17 @@ int check_frame_counters(frr_ctx *c, Counters *host)
 
 template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks)
 {
-    { ProfScope p(c, KID_GEOM_COUNT); hipLaunchKernelGGL(k_geom_count<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
-    { ProfScope p(c, KID_SCAN_BLOCKS); hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, nblocks, g.cap, g.ntris, g.cnt); }
-    { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL(k_geom_emit<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
+    if (c->geom_twopass) {
+        { ProfScope p(c, KID_GEOM_COUNT); hipLaunchKernelGGL(k_geom_count<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
+        { ProfScope p(c, KID_SCAN_BLOCKS); hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, nblocks, g.cap, g.ntris, g.cnt); }
+        { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, false>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
+    } else {
+        { ProfScope p(c, KID_SCAN_BLOCKS);
+          hipLaunchKernelGGL(k_geom_begin, dim3(std::min<uint32_t>((nblocks + 255) / 256, 64)), dim3(256), 0, c->stream, g.status, nblocks, g.ntris, g.cnt); }
+        { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, true>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
+    }
     { ProfScope p(c, KID_GEOM_EMIT_CLIP);
-      uint32_t gb = (uint32_t)std::min<uint64_t>((g.ntris + 63) / 64, 1024);
+      uint32_t gb = (uint32_t)std::min<uint64_t>((g.ntris + 63) / 64, 256); // one wave per CU; scratch-heavy
       hipLaunchKernelGGL(k_geom_emit_clip<VS>, dim3(gb), dim3(64), 0, c->stream, g, c->duni); }
 }
 
@@ -243,6 +253,8 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     frr_ctx *c = new frr_ctx();
     c->device = device; c->W = width; c->H = height;
     { const char *e = getenv("FRR_RASTER"); c->raster_sweep = e && strcmp(e, "sweep") == 0; }
+    { const char *e = getenv("FRR_GEOM"); c->geom_twopass = !(e && strcmp(e, "lookback") == 0); }
+    { const char *e = getenv("FRR_BIN_G"); c->bin_g = e ? atoi(e) : 0; }
     if (stream) c->stream = (hipStream_t)stream;
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FRR_ERR_HIP; } c->own_stream = true; }
     const size_t npx = (size_t)width * height;
@@ -280,7 +292,7 @@ void frr_destroy(frr_ctx *c)
     prof_collect(c);
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
-    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->clip_list, c->recs, c->vary,
+    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->lb_status, c->clip_list, c->recs, c->vary, c->pbox,
                     c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bins2, c->bin_matrix};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -419,14 +431,16 @@ int frr_geometry(frr_ctx *c, int mesh, uint64_t *ntris_setup)
     const uint32_t nblocks = (uint32_t)((nt + GEOM_BLOCK - 1) / GEOM_BLOCK);
     int rc;
     if ((rc = ensure(c, c->block_sums, c->block_sums_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
+    if ((rc = ensure(c, c->lb_status, c->lb_status_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
     if ((rc = ensure(c, c->clip_list, c->clip_cap, (size_t)nt + 1)) != FRR_OK) return rc;
     if ((rc = ensure(c, c->recs, c->setup_cap, (size_t)cap)) != FRR_OK) return rc;
+    if ((rc = ensure(c, c->pbox, c->pbox_cap, c->setup_cap)) != FRR_OK) return rc;
     if (K > 0 && (rc = ensure(c, c->vary, c->vary_cap, (size_t)c->setup_cap * 3 * 8 /* K <= 8 in the shader table */)) != FRR_OK) return rc;
     GeomArgs g;
     g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
     g.cap = (uint32_t)std::min<size_t>(c->setup_cap, K > 0 ? c->vary_cap / (3 * (size_t)K) : c->setup_cap);
-    g.block_sums = c->block_sums; g.clip_list = c->clip_list; g.clip_cap = (uint32_t)c->clip_cap;
-    g.recs = c->recs; g.vary = c->vary; g.cnt = c->cnt;
+    g.block_sums = c->block_sums; g.status = c->lb_status; g.clip_list = c->clip_list; g.clip_cap = (uint32_t)c->clip_cap;
+    g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;
     if (nt == 0) {
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, 0u, g.cap, 0u, g.cnt);
     } else {
@@ -453,6 +467,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     if (x0 > x1 || y0 > y1) return fail(c, FRR_ERR_INVALID, "range min > max (i32::clamp would panic, renderer.rs:285)");
     const int64_t ww = (int64_t)x1 - x0, wh = (int64_t)y1 - y0;
     if (ww > (int64_t)c->W || wh > (int64_t)c->H) return fail(c, FRR_ERR_INVALID, "window larger than the FrameBuffer");
+    if (x0 < -32768 || y0 < -32768 || x1 > 32767 || y1 > 32767) return fail(c, FRR_ERR_UNSUPPORTED, "window coordinates outside the i16 range");
     if (ww > 0 && wh > 0 && (x1 <= 0 || (wh - 1) * (int64_t)x1 + ww > (int64_t)c->W * c->H))
         return fail(c, FRR_ERR_INVALID, "depth index (cy-y0)*x1+(cx-x0) would leave the depth buffer (renderer.rs:362)");
     const int K = frr_vs_num_varyings(c->geom_vs);
@@ -466,7 +481,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     a.cstride = (int)c->W; a.dstride = x1;
     a.tiles_x = (int)((ww + TILE - 1) / TILE); a.tiles_y = (int)((wh + TILE - 1) / TILE);
     a.rank = c->rank; a.world = c->world;
-    a.recs = c->recs; a.vary = c->vary;
+    a.recs = c->recs; a.vary = c->vary; a.pbox = c->pbox;
     a.tile_counts = c->tile_counts; a.tile_offsets = c->tile_offsets; a.tile_cursor = c->tile_cursor;
     const uint32_t ntiles = (uint32_t)a.tiles_x * a.tiles_y;
     int rc;
@@ -480,7 +495,8 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     a.color = c->color; a.depth = c->depth; a.tri_id = c->tri_id; a.cnt = c->cnt;
     if (ntiles <= BIN_LDS_MAX_TILES) {
         // LDS multi-split (no global atomics): G chunk workgroups, ~3K triangles each
-        const uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + 3071) / 3072, 1), BIN_MAX_G);
+        uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + 3071) / 3072, 1), BIN_MAX_G);
+        if (c->bin_g > 0) G = (uint32_t)std::min(c->bin_g, BIN_MAX_G);
         if ((rc = ensure(c, c->bin_matrix, c->bin_matrix_cap, (size_t)BIN_MAX_G * c->max_tiles)) != FRR_OK) return rc;
         const size_t lds = (size_t)ntiles * sizeof(uint32_t);
         if (!c->lds_attr_set) {

@@ -36,6 +36,8 @@ struct Counters {
     uint64_t bin_entries_frame;
     uint32_t draws;
     uint32_t need_setup;    // setup triangles the current draw needs (valid even on overflow)
+    uint32_t ticket;        // dynamic block ids of the single-pass geometry kernel
+    uint32_t pad0;
     unsigned long long dbg[8]; // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py)
 };
 
@@ -56,11 +58,13 @@ struct GeomArgs {
     uint32_t ntris;
     uint32_t width, height; // viewport of renderer.rs:107-108
     uint32_t cap;           // setup capacity (triangles)
-    uint32_t *block_sums;   // [nblocks], exclusive-scanned in place
+    uint32_t *block_sums;   // [nblocks], exclusive-scanned in place (two-pass path)
+    unsigned long long *status; // [nblocks] look-back status words (single-pass path)
     uint2 *clip_list;       // (input index, output offset)
     uint32_t clip_cap;
     RasterRec *recs;
     float *vary;
+    uint2 *pbox;            // per setup triangle: pixel bbox of spi as 4 x i16 (minx|miny<<16, maxx|maxy<<16)
     Counters *cnt;
 };
 
@@ -72,6 +76,7 @@ struct RasterArgs {
     int32_t rank, world;              // tile-row ownership (ty % world == rank)
     const RasterRec *recs;
     const float *vary;
+    const uint2 *pbox;
     uint32_t *tile_counts;            // [ntiles]
     uint32_t *tile_offsets;           // [ntiles+1]
     uint32_t *tile_cursor;            // [ntiles]
@@ -222,10 +227,20 @@ __device__ __forceinline__ bool is_top_left(int ax, int ay, int bx, int by)
     return ((ay == by) && (ax < bx)) || (ay > by);
 }
 
+// Pixel bbox of a setup triangle for the binning passes: 4 x i16, saturated (the raster window is
+// required to lie within the i16 range, so saturating first and clamping to the window later is the
+// same as renderer.rs:285-298's clamp of the i32 values).
+__device__ __forceinline__ uint2 pack_pbox(int x0, int y0, int x1, int y1, int x2, int y2)
+{
+    auto s16 = [](int v) { return (uint32_t)min(max(v, -32768), 32767) & 0xFFFFu; };
+    const int mnx = min(x0, min(x1, x2)), mny = min(y0, min(y1, y2)), mxx = max(x0, max(x1, x2)), mxy = max(y0, max(y1, y2));
+    return make_uint2(s16(mnx) | (s16(mny) << 16), s16(mxx) | (s16(mxy) << 16));
+}
+
 // Orientation (renderer.rs:300-312) + top-left flags (:318-320) + record store, for one emitted
 // triangle whose vertices v0,v1,v2 are in emission order.
 template <int K>
-__device__ __forceinline__ void store_setup(RasterRec *__restrict__ recs, float *__restrict__ vary, uint32_t idx,
+__device__ __forceinline__ void store_setup(RasterRec *__restrict__ recs, float *__restrict__ vary, uint2 *__restrict__ pbox, uint32_t idx,
                                             const ScreenVtx &v0, ScreenVtx v1, ScreenVtx v2, const float *c0,
                                             const float *c1, const float *c2)
 {
@@ -238,6 +253,7 @@ __device__ __forceinline__ void store_setup(RasterRec *__restrict__ recs, float 
     flags |= is_top_left(v0.ix, v0.iy, v1.ix, v1.iy) ? 0u : 2u;
     flags |= is_top_left(v1.ix, v1.iy, v2.ix, v2.iy) ? 0u : 4u;
     flags |= is_top_left(v2.ix, v2.iy, v0.ix, v0.iy) ? 0u : 8u;
+    pbox[idx] = pack_pbox(v0.ix, v0.iy, v1.ix, v1.iy, v2.ix, v2.iy);
     uint4 *dst = reinterpret_cast<uint4 *>(recs + idx);
     dst[0] = make_uint4((uint32_t)v0.ix, (uint32_t)v0.iy, (uint32_t)v1.ix, (uint32_t)v1.iy);
     dst[1] = make_uint4((uint32_t)v2.ix, (uint32_t)v2.iy, f2u(v0.sx), f2u(v0.sy));

@@ -126,12 +126,67 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *__restrict__ sum
 // then the per-triangle prologue of rasterization (:300-320) so the record is ready to scan.
 // Clipped triangles only reserve their output range and go to the clip work list.
 // ---------------------------------------------------------------------------------------------
-template <int VS>
+// Single-pass variant (LOOKBACK): the block offsets come from a decoupled look-back scan over
+// 64-bit status words {flag:2, value:62} (flag 1 = block aggregate, 2 = inclusive prefix), so the
+// inputs are read once and k_geom_count / k_scan_blocks are not launched.  Block ids are handed out
+// by an atomic ticket, so a block only ever waits for blocks that have already started.
+constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
+
+__global__ __launch_bounds__(256) void k_geom_begin(unsigned long long *status, uint32_t nblocks, uint32_t ntris, Counters *cnt)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nblocks; i += gridDim.x * 256u) status[i] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        cnt->tri_base += cnt->n_setup; // previous draw's triangles precede this draw's in the frame
+        cnt->n_clip = 0;
+        cnt->ticket = 0;
+        cnt->tris_in += ntris;
+        cnt->draws += 1;
+    }
+}
+
+// wave 0 of block b: exclusive prefix of the block totals; publishes this block's status
+__device__ __forceinline__ uint32_t lookback_exclusive(unsigned long long *st, uint32_t b, uint32_t my_total, int lane)
+{
+    if (b == 0) {
+        if (lane == 0) __hip_atomic_store(&st[0], LB_PREFIX | my_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&st[b], LB_AGG | my_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0;
+    int j = (int)b - 1; // nearest predecessor not yet accounted for
+    for (;;) {
+        const int idx = j - lane;
+        // the virtual block -1 carries prefix 0
+        const unsigned long long v = idx >= 0 ? __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;
+        const uint32_t flag = (uint32_t)(v >> 62);
+        const unsigned long long m_empty = __ballot(flag == 0u), m_prefix = __ballot(flag == 2u);
+        const int first_prefix = m_prefix ? __builtin_ctzll(m_prefix) : 64;
+        const int first_empty = m_empty ? __builtin_ctzll(m_empty) : 64;
+        const bool done = first_prefix < first_empty;              // a prefix is reachable through aggregates only
+        const int take = done ? first_prefix + 1 : first_empty;    // lanes [0, take) are usable now
+        const uint32_t part = wave_incl_scan(lane < take ? (uint32_t)(v & LB_VALUE) : 0u);
+        excl += (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
+        if (done) break;
+        j -= take;
+        if (take == 0) __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane == 0) __hip_atomic_store(&st[b], LB_PREFIX | (unsigned long long)(excl + my_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+template <int VS, bool LOOKBACK>
 __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniforms u)
 {
     __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_bid, s_base;
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K;
-    const uint32_t t = blockIdx.x * GEOM_BLOCK + threadIdx.x;
+    uint32_t bid = blockIdx.x;
+    if constexpr (LOOKBACK) {
+        if (threadIdx.x == 0) s_bid = atomicAdd(&g.cnt->ticket, 1u);
+        __syncthreads();
+        bid = s_bid;
+    }
+    const uint32_t t = bid * GEOM_BLOCK + threadIdx.x;
     float pos[3][4];
     float ctx[3][K > 0 ? K : 1];
     uint32_t n = 0;
@@ -143,8 +198,27 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
         n = classify(pos, clipped);
     }
     uint32_t total;
-    const uint32_t off = g.block_sums[blockIdx.x] + block_excl_scan256(n, s_w, total);
-    if (n == 0 || g.cnt->n_setup == 0) return; // n_setup == 0: nothing to emit or capacity overflow
+    uint32_t off = block_excl_scan256(n, s_w, total);
+    if constexpr (LOOKBACK) {
+        if (threadIdx.x < 64) {
+            const uint32_t excl = lookback_exclusive(g.status, bid, total, (int)threadIdx.x);
+            if (threadIdx.x == 0) {
+                s_base = excl;
+                if (bid == gridDim.x - 1) { // the last block knows the grand total
+                    const uint32_t all = excl + total;
+                    g.cnt->need_setup = all;
+                    if (all > g.cap) atomicOr(&g.cnt->overflow, 1u);
+                    g.cnt->n_setup = all > g.cap ? 0u : all;
+                }
+            }
+        }
+        __syncthreads();
+        off += s_base;
+        if (n == 0 || off + n > g.cap) return; // nothing to emit / capacity overflow (frame flagged invalid)
+    } else {
+        off += g.block_sums[blockIdx.x];
+        if (n == 0 || g.cnt->n_setup == 0) return; // n_setup == 0: nothing to emit or capacity overflow
+    }
     if (clipped) {
         uint32_t slot = atomicAdd(&g.cnt->n_clip, 1u);
         if (slot < g.clip_cap) g.clip_list[slot] = make_uint2(t, off);
@@ -165,18 +239,46 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
     int r1 = (key[0] <= key[1]) + (key[2] < key[1]);
     // (the third rank is implied by the other two)
     const float fw = (float)g.width, fh = (float)g.height;
-    ScreenVtx s0 = to_screen(pos[0], fw, fh), s1 = to_screen(pos[1], fw, fh), s2 = to_screen(pos[2], fw, fh);
-    // vertex with rank r
-    auto pick = [&](int r) { return r0 == r ? s0 : (r1 == r ? s1 : s2); };
-    ScreenVtx a = pick(0), b = pick(1), c = pick(2);
-    float ca[K > 0 ? K : 1], cb[K > 0 ? K : 1], cc[K > 0 ? K : 1];
+    const ScreenVtx s0 = to_screen(pos[0], fw, fh), s1 = to_screen(pos[1], fw, fh), s2 = to_screen(pos[2], fw, fh);
+    // Everything below is a permutation of the three vertices: sorted order, then the orientation
+    // swap of renderer.rs:300-312.  It is written as scalar selects on the destination slot of each
+    // input vertex (struct-valued selects end up as runtime-indexed scratch).
+    auto by_rank = [&](int r, float x0, float x1, float x2) { return r0 == r ? x0 : (r1 == r ? x1 : x2); };
+    const float ax = by_rank(0, s0.ndcx, s1.ndcx, s2.ndcx), ay = by_rank(0, s0.ndcy, s1.ndcy, s2.ndcy);
+    const float bx = by_rank(1, s0.ndcx, s1.ndcx, s2.ndcx), by = by_rank(1, s0.ndcy, s1.ndcy, s2.ndcy);
+    const float cx2 = by_rank(2, s0.ndcx, s1.ndcx, s2.ndcx), cy2 = by_rank(2, s0.ndcy, s1.ndcy, s2.ndcy);
+    const float v01x = bx - ax, v01y = by - ay, v02x = cx2 - ax, v02y = cy2 - ay;
+    const bool swap = (v01x * v02y - v02x * v01y) > 0.0f;                 // :300-309
+    const int r2 = 3 - r0 - r1;
+    auto slot_of = [&](int r) { return r == 0 ? 0 : ((r == 1) != swap ? 1 : 2); };
+    const int d0 = slot_of(r0), d1 = slot_of(r1), d2 = slot_of(r2);      // destination slot of input vertex i
+    auto in_slot_f = [&](int s, float x0, float x1, float x2) { return d0 == s ? x0 : (d1 == s ? x1 : x2); };
+    auto in_slot_i = [&](int s, int x0, int x1, int x2) { return d0 == s ? x0 : (d1 == s ? x1 : x2); };
+    int px[3], py[3];
+    float sx[3], sy[3], rw[3];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        ca[k] = r0 == 0 ? ctx[0][k] : (r1 == 0 ? ctx[1][k] : ctx[2][k]);
-        cb[k] = r0 == 1 ? ctx[0][k] : (r1 == 1 ? ctx[1][k] : ctx[2][k]);
-        cc[k] = r0 == 2 ? ctx[0][k] : (r1 == 2 ? ctx[1][k] : ctx[2][k]);
+    for (int s = 0; s < 3; ++s) {
+        px[s] = in_slot_i(s, s0.ix, s1.ix, s2.ix); py[s] = in_slot_i(s, s0.iy, s1.iy, s2.iy);
+        sx[s] = in_slot_f(s, s0.sx, s1.sx, s2.sx); sy[s] = in_slot_f(s, s0.sy, s1.sy, s2.sy);
+        rw[s] = in_slot_f(s, s0.rhw, s1.rhw, s2.rhw);
     }
-    store_setup<K>(g.recs, g.vary, off, a, b, c, ca, cb, cc);
+    uint32_t flags = swap ? 1u : 0u;
+    flags |= is_top_left(px[0], py[0], px[1], py[1]) ? 0u : 2u;           // :318-320
+    flags |= is_top_left(px[1], py[1], px[2], py[2]) ? 0u : 4u;
+    flags |= is_top_left(px[2], py[2], px[0], py[0]) ? 0u : 8u;
+    g.pbox[off] = pack_pbox(px[0], py[0], px[1], py[1], px[2], py[2]);
+    uint4 *dst = reinterpret_cast<uint4 *>(g.recs + off);
+    dst[0] = make_uint4((uint32_t)px[0], (uint32_t)py[0], (uint32_t)px[1], (uint32_t)py[1]);
+    dst[1] = make_uint4((uint32_t)px[2], (uint32_t)py[2], f2u(sx[0]), f2u(sy[0]));
+    dst[2] = make_uint4(f2u(sx[1]), f2u(sy[1]), f2u(sx[2]), f2u(sy[2]));
+    dst[3] = make_uint4(f2u(rw[0]), f2u(rw[1]), f2u(rw[2]), flags);
+    if constexpr (K > 0) {
+        float *o = g.vary + (size_t)off * (3 * K);
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int k = 0; k < K; ++k) o[s * K + k] = in_slot_f(s, ctx[0][k], ctx[1][k], ctx[2][k]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -241,7 +343,7 @@ __global__ __launch_bounds__(64) void k_geom_emit_clip(GeomArgs g, DevUniforms u
         auto emit = [&](uint32_t idx, int i0, int i1, int i2) {
             const int a = ord[i0], b = ord[i1], c = ord[i2];
             ScreenVtx sa = to_screen(vpos[a], fw, fh), sb = to_screen(vpos[b], fw, fh), sc = to_screen(vpos[c], fw, fh);
-            store_setup<K>(g.recs, g.vary, idx, sa, sb, sc, vctx[a], vctx[b], vctx[c]);
+            store_setup<K>(g.recs, g.vary, g.pbox, idx, sa, sb, sc, vctx[a], vctx[b], vctx[c]);
         };
         uint32_t idx = item.y;
         if (n == 3) { emit(idx, 0, 1, 2); continue; }       // :237-243 (cannot happen for clipped, kept)
@@ -263,12 +365,12 @@ struct TileRange { int tx0, tx1, ty0, ty1; }; // inclusive-exclusive tile ranges
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
-__device__ __forceinline__ TileRange tri_tiles(const RasterArgs &a, const RasterRec *__restrict__ r)
+__device__ __forceinline__ TileRange tiles_of_pbox(const RasterArgs &a, const uint2 b)
 {
-    const int4 q0 = *reinterpret_cast<const int4 *>(r);       // p0.x p0.y p1.x p1.y
-    const int2 q1 = *reinterpret_cast<const int2 *>(&r->p[4]); // p2.x p2.y
-    int minx = clampi(min(q0.x, min(q0.z, q1.x)), a.x0, a.x1), maxx = clampi(max(q0.x, max(q0.z, q1.x)), a.x0, a.x1);
-    int miny = clampi(min(q0.y, min(q0.w, q1.y)), a.y0, a.y1), maxy = clampi(max(q0.y, max(q0.w, q1.y)), a.y0, a.y1);
+    const int mnx = (int)(short)(b.x & 0xFFFFu), mny = (int)(short)(b.x >> 16);
+    const int mxx = (int)(short)(b.y & 0xFFFFu), mxy = (int)(short)(b.y >> 16);
+    const int minx = clampi(mnx, a.x0, a.x1), maxx = clampi(mxx, a.x0, a.x1);
+    const int miny = clampi(mny, a.y0, a.y1), maxy = clampi(mxy, a.y0, a.y1);
     TileRange t;
     if (maxx <= minx || maxy <= miny) { t.tx0 = t.tx1 = t.ty0 = t.ty1 = 0; return t; }
     t.tx0 = (minx - a.x0) / TILE; t.tx1 = (maxx - 1 - a.x0) / TILE + 1;
@@ -286,7 +388,7 @@ __global__ __launch_bounds__(256) void k_bin(RasterArgs a)
     for (uint32_t base = wave * 64u; base < n; base += nwaves * 64u) {
         const uint32_t i = base + lane;
         TileRange t = {0, 0, 0, 0};
-        if (i < n) t = tri_tiles(a, a.recs + i);
+        if (i < n) t = tiles_of_pbox(a, a.pbox[i]);
         const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
         const int nt = ntx * nty;
         auto visit = [&](uint32_t tri, int tx, int ty) {
@@ -375,31 +477,42 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_lds(RasterArgs a, uint32_t ntile
     const uint32_t lo = min(n, g * chunk), hi = min(n, lo + chunk);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (uint32_t base = lo + wave * 64u; base < hi; base += (BIN_WG / 64) * 64u) {
-        const uint32_t i = base + lane;
-        TileRange t = {0, 0, 0, 0};
-        if (i < hi) t = tri_tiles(a, a.recs + i);
-        const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
-        const int nt = ntx * nty;
-        auto visit = [&](uint32_t tri, int tx, int ty) {
-            if (ty % a.world != a.rank) return;
-            const int tile = ty * a.tiles_x + tx;
-            if constexpr (SCATTER) {
-                const uint32_t pos = atomicAdd(&s_hist[tile], 1u);
-                if (pos < a.bin_cap) a.bins[pos] = tri;
-            } else {
-                atomicAdd(&s_hist[tile], 1u);
+    constexpr int PF = 4; // bboxes of PF rounds are fetched up front: the loop is latency-bound otherwise
+    for (uint32_t base0 = lo + wave * 64u; base0 < hi; base0 += PF * BIN_WG) {
+        uint2 pb[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const uint32_t i = base0 + k * BIN_WG + lane;
+            pb[k] = i < hi ? a.pbox[i] : make_uint2(0u, 0u); // (0,0)-(0,0) is an empty box
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const uint32_t base = base0 + k * BIN_WG;
+            if (base >= hi) break;
+            const uint32_t i = base + lane;
+            const TileRange t = tiles_of_pbox(a, pb[k]);
+            const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
+            const int nt = ntx * nty;
+            auto visit = [&](uint32_t tri, int tx, int ty) {
+                if (ty % a.world != a.rank) return;
+                const int tile = ty * a.tiles_x + tx;
+                if constexpr (SCATTER) {
+                    const uint32_t pos = atomicAdd(&s_hist[tile], 1u);
+                    if (pos < a.bin_cap) a.bins[pos] = tri;
+                } else {
+                    atomicAdd(&s_hist[tile], 1u);
+                }
+            };
+            if (nt > 0 && nt <= BIN_COOP)
+                for (int ty = t.ty0; ty < t.ty1; ++ty)
+                    for (int tx = t.tx0; tx < t.tx1; ++tx) visit(i, tx, ty);
+            unsigned long long big = __ballot(nt > BIN_COOP);
+            while (big) {
+                const int src = __builtin_ctzll(big);
+                big &= big - 1;
+                const int bx0 = __shfl(t.tx0, src), by0 = __shfl(t.ty0, src), bnx = __shfl(ntx, src), bnt = __shfl(nt, src);
+                for (int q = lane; q < bnt; q += 64) visit(base + src, bx0 + q % bnx, by0 + q / bnx);
             }
-        };
-        if (nt > 0 && nt <= BIN_COOP)
-            for (int ty = t.ty0; ty < t.ty1; ++ty)
-                for (int tx = t.tx0; tx < t.tx1; ++tx) visit(i, tx, ty);
-        unsigned long long big = __ballot(nt > BIN_COOP);
-        while (big) {
-            const int src = __builtin_ctzll(big);
-            big &= big - 1;
-            const int bx0 = __shfl(t.tx0, src), by0 = __shfl(t.ty0, src), bnx = __shfl(ntx, src), bnt = __shfl(nt, src);
-            for (int k = lane; k < bnt; k += 64) visit(base + src, bx0 + k % bnx, by0 + k / bnx);
         }
     }
     if constexpr (!SCATTER) {
@@ -418,7 +531,13 @@ __global__ __launch_bounds__(256) void k_bin_colscan(uint32_t *__restrict__ M, u
     const uint32_t tl = threadIdx.x & 31, gs = threadIdx.x >> 5;
     const uint32_t t = blockIdx.x * 32 + tl;
     const bool ok = t < ntiles;
-    for (uint32_t g = gs; g < G; g += 8) s[g][tl] = ok ? M[(size_t)g * ntiles + t] : 0u;
+    {
+        uint32_t v[BIN_MAX_G / 8];
+#pragma unroll
+        for (int k = 0; k < BIN_MAX_G / 8; ++k) { const uint32_t g = gs + 8u * k; v[k] = (ok && g < G) ? M[(size_t)g * ntiles + t] : 0u; }
+#pragma unroll
+        for (int k = 0; k < BIN_MAX_G / 8; ++k) { const uint32_t g = gs + 8u * k; if (g < G) s[g][tl] = v[k]; }
+    }
     __syncthreads();
     const uint32_t seg = (G + 7) / 8, g0 = min(G, gs * seg), g1 = min(G, g0 + seg);
     uint32_t sum = 0;
