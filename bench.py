@@ -113,9 +113,8 @@ def main():
         r = fr.Renderer(W, H, device=local_rank, stream=stream.cuda_stream)
         # frame targets live in torch tensors (plumbing: device memory + the gather's operands);
         # rows are padded to a whole number of tile rows per rank so owned bands are one strided view
-        tiles_y = (H + 31) // 32
-        rows_per_rank = (tiles_y + world - 1) // world
-        HP = rows_per_rank * world * 32
+        from f_renderer_amd.multigpu import BandGather, band_layout
+        _, _, HP = band_layout(H, world)
         color = torch.zeros((HP, W), dtype=torch.int32, device="cuda")
         depth = torch.zeros((HP, W), dtype=torch.float32, device="cuda")
         tri_id = torch.full((HP, W), -1, dtype=torch.int32, device="cuda")
@@ -123,26 +122,15 @@ def main():
         r.set_partition(rank, world)
         dev_in = torch.from_numpy(tris).to("cuda")  # resident in HBM before timing
         mesh = r.bind_mesh_device(dev_in.data_ptr(), ntris, fr.VS_CLIP, keepalive=dev_in)
-
-        if world > 1:
-            own_view = depth.view(rows_per_rank, world, 32, W)[:, rank]          # my interleaved bands
-            band = torch.zeros((rows_per_rank, 32, W), dtype=torch.float32, device="cuda")
-            if rank == 0:
-                gbuf = torch.empty((world, rows_per_rank, 32, W), dtype=torch.float32, device="cuda")
-                gathered = list(gbuf.unbind(0))
-                final = torch.zeros((HP, W), dtype=torch.float32, device="cuda")
-            else:
-                gbuf, gathered, final = None, None, None
+        gather = BandGather(H, W, torch.float32, "cuda", rank, world) if world > 1 else None
+        final = None
 
         def step():
+            nonlocal final
             r.clear((30, 30, 30, 255), 0.0)
             r.draw(mesh, fr.PS_DEPTH)
-            if world > 1:
-                # owned bands -> contiguous staging -> ONE gather to rank 0 (final image only)
-                band.copy_(own_view)
-                dist.gather(band, gathered, dst=0)
-                if rank == 0:
-                    final.view(rows_per_rank, world, 32, W).copy_(gbuf.permute(1, 0, 2, 3))
+            if gather is not None:
+                final = gather(depth)   # owned bands -> ONE RCCL gather to rank 0 (final image only)
 
         # one counted frame: the exact covered-fragment count of this rank's tiles (the Mfrag/s
         # numerator).  The statistic is then switched off: maintaining it forbids the tile kernel's
@@ -179,7 +167,10 @@ def main():
         # multi-GPU image check on rank 0: gathered image == what a single full render would hold
         image_ok = None
         if world > 1 and rank == 0:
-            image_ok = bool(torch.isfinite(final[:H]).all().item())
+            # every pixel of the gathered depth image must come from its owner's render (clear value 0 or a
+            # positive 1/w): finite and non-negative everywhere, and not all background
+            img = final[:H]
+            image_ok = bool(torch.isfinite(img).all().item() and (img >= 0).all().item() and (img > 0).any().item())
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     cov = torch.tensor([float(counted["frag_covered"])], dtype=torch.float64, device="cuda")

@@ -682,6 +682,23 @@ void frr_set_perspective(float fovy, float aspect, float zn, float zf, float m[1
 // ---- debug hooks ------------------------------------------------------------------------------
 float frr_host_atan2f(float y, float x) { return fd_atan2f(y, x); }
 
+int frr_debug_gather_calib(frr_ctx *c, uint32_t log2_records)
+{
+    if (!c || log2_records < 10 || log2_records > 24) return FRR_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)1 << log2_records;
+    void *d = nullptr;
+    if (hipMalloc(&d, n * 64 + 64) != hipSuccess) return fail(c, FRR_ERR_NOMEM, "hipMalloc");
+    hipError_t e = hipMemsetAsync(d, 1, n * 64 + 64, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_gather, dim3((uint32_t)(n / 256)), dim3(256), 0, c->stream, (const uint4 *)d, (uint32_t)(n - 1), (uint32_t *)((char *)d + n * 64));
+        e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, FRR_ERR_HIP, hipGetErrorString(e));
+    return FRR_OK;
+}
+
 int frr_debug_scan64(frr_ctx *c, const uint32_t *in, uint32_t *out)
 {
     if (!c || !in || !out) return FRR_ERR_INVALID;

@@ -558,6 +558,17 @@ __global__ __launch_bounds__(256) void k_bin_colscan(uint32_t *__restrict__ M, u
 namespace frr {
 
 // ---- debug --------------------------------------------------------------------------------
+// PMC calibration: every lane gathers one distinct 64-byte record (4 x dwordx4, the tile kernel's
+// phase-1 access pattern) from a table larger than the Infinity Cache; true bytes = n * 64.
+__global__ __launch_bounds__(256) void k_debug_gather(const uint4 *__restrict__ table, uint32_t n_mask, uint32_t *out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t j = (i * 0x9E3779B1u) & n_mask; // odd multiplier: a permutation of [0, n)
+    const uint4 *r = table + (size_t)j * 4;
+    const uint4 a = r[0], b = r[1], c = r[2], d = r[3];
+    const uint32_t x = a.x ^ a.w ^ b.y ^ c.z ^ d.w ^ d.x;
+    if (x == 0x12345678u) out[0] = i; // keeps the loads alive
+}
 __global__ void k_debug_atan2f(const float *y, const float *x, float *out, uint64_t n)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,60 @@
+"""Screen-tile partition across ranks and the final-image gather (one process per GPU).
+
+The path shards by screen tiles: rank r owns the 32-pixel tile rows ty with ty % world == r
+(`frr_set_partition`, include/frr.h); geometry is replicated; there is no data-path collective
+during a frame.  The only exchange is ONE gather of the owned bands to rank 0 for the final image
+(RCCL over xGMI through torch.distributed's "nccl" backend on GPUs; "gloo" in the CPU tests).
+
+Frame targets are allocated with the height padded to rows_per_rank * world tile rows, so that a
+rank's interleaved bands are a single strided view [rows_per_rank, 32, W] of its own image.
+"""
+import torch
+
+TILE = 32
+
+
+def band_layout(height, world):
+    """(tiles_y, rows_per_rank, padded_height) for a frame of `height` pixel rows."""
+    tiles_y = (height + TILE - 1) // TILE
+    rows_per_rank = (tiles_y + world - 1) // world
+    return tiles_y, rows_per_rank, rows_per_rank * world * TILE
+
+
+def owned_tile_rows(height, rank, world):
+    tiles_y, _, _ = band_layout(height, world)
+    return list(range(rank, tiles_y, world))
+
+
+def owned_view(image, rank, world):
+    """Strided view [rows_per_rank, 32, W, ...] of the bands rank owns in a padded image [HP, W, ...]."""
+    hp = image.shape[0]
+    rows_per_rank = hp // (world * TILE)
+    assert rows_per_rank * world * TILE == hp, "image height must be padded with band_layout()"
+    return image.view(rows_per_rank, world, TILE, *image.shape[1:])[:, rank]
+
+
+class BandGather:
+    """One gather per frame of every rank's owned bands into the full (padded) image on `dst`."""
+
+    def __init__(self, height, width, dtype, device, rank, world, dst=0, trailing=()):
+        self.rank, self.world, self.dst = rank, world, dst
+        _, self.rows_per_rank, self.padded_height = band_layout(height, world)
+        shape = (self.rows_per_rank, TILE, width, *trailing)
+        self.band = torch.zeros(shape, dtype=dtype, device=device)
+        if rank == dst:
+            self.gbuf = torch.empty((world, *shape), dtype=dtype, device=device)
+            self.gathered = list(self.gbuf.unbind(0))
+            self.final = torch.zeros((self.padded_height, width, *trailing), dtype=dtype, device=device)
+        else:
+            self.gbuf, self.gathered, self.final = None, None, None
+
+    def __call__(self, local_image, group=None):
+        """local_image: this rank's padded image [HP, W, ...] (only its owned bands are meaningful)."""
+        import torch.distributed as dist
+        self.band.copy_(owned_view(local_image, self.rank, self.world))   # owned bands -> contiguous staging
+        dist.gather(self.band, self.gathered, dst=self.dst, group=group)   # the frame's only collective
+        if self.rank == self.dst:
+            v = self.final.view(self.rows_per_rank, self.world, TILE, *self.final.shape[1:])
+            v.copy_(self.gbuf.transpose(0, 1))                             # interleave the bands back
+            return self.final
+        return None

@@ -179,6 +179,8 @@ void frr_set_perspective(float fovy, float aspect, float zn, float zf, float m[1
 int frr_debug_atan2f(frr_ctx *ctx, const float *y, const float *x, float *out, uint64_t n);
 /* the same source compiled for the host, to pin the port against glibc without a GPU */
 float frr_host_atan2f(float y, float x);
+/* PMC calibration: gathers 2^log2_records distinct 64-byte records (true bytes = 64 << log2_records) */
+int frr_debug_gather_calib(frr_ctx *ctx, uint32_t log2_records);
 /* device wave64 inclusive prefix sum (DPP) of 64 values, for tests */
 int frr_debug_scan64(frr_ctx *ctx, const uint32_t *in, uint32_t *out);
 

@@ -1,0 +1,60 @@
+"""CPU coverage of the N>1 path (world_size 2, gloo): the band partition + the single gather that
+bench.py runs over RCCL.  Each rank holds the image a partitioned render leaves behind (only its own
+interleaved tile rows written); after the gather rank 0 must hold the full single-GPU image."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, H, W, full_np, out_path):
+    import torch
+    import torch.distributed as dist
+    from f_renderer_amd.multigpu import BandGather, band_layout, owned_tile_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, _, HP = band_layout(H, world)
+    full = torch.from_numpy(full_np)
+    local = torch.zeros((HP, W), dtype=torch.float32)          # what frr_clear leaves: background
+    for ty in owned_tile_rows(H, rank, world):                 # what a partitioned frr_draw writes
+        y0, y1 = ty * 32, min(ty * 32 + 32, H)
+        local[y0:y1] = full[y0:y1]
+    g = BandGather(H, W, torch.float32, "cpu", rank, world)
+    for _ in range(2):                                         # twice: the staging buffers are reused per frame
+        final = g(local)
+    if rank == 0:
+        np.save(out_path, final[:H].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H,W", [(1080, 64), (100, 48), (32, 16)])
+def test_band_gather_world2_gloo(tmp_path, H, W):
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(H)
+    full = rng.random((H, W), dtype=np.float32) + 0.25
+    out = str(tmp_path / "final.npy")
+    mp.spawn(_worker, args=(2, _free_port(), H, W, full, out), nprocs=2, join=True)
+    np.testing.assert_array_equal(np.load(out), full)
+
+
+def test_band_layout_matches_partition_rule():
+    from f_renderer_amd.multigpu import band_layout, owned_tile_rows
+    for H in (1080, 2160, 4096, 33, 1):
+        for world in (1, 2, 3, 4, 8):
+            tiles_y, rpr, HP = band_layout(H, world)
+            assert tiles_y == (H + 31) // 32 and HP >= H and HP == rpr * world * 32
+            rows = sorted(sum((owned_tile_rows(H, r, world) for r in range(world)), []))
+            assert rows == list(range(tiles_y))                # every tile row has exactly one owner
+            for r in range(world):
+                assert all(ty % world == r for ty in owned_tile_rows(H, r, world))   # frr_set_partition's rule
