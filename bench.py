@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="random_1M_tris_1920x1080_depth", choices=sorted(WORKLOADS))
+    ap.add_argument("--force-dist", action="store_true",
+                    help="dev: initialise RCCL and run the band gather even with one rank (exercises the N>1 code path)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0,
                     help="approximate CPU time budget of the oracle baseline leg (rank 0, N=1 only); 0 disables")
     return ap.parse_args()
@@ -100,9 +102,14 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W, H, ntris, _, _ = WORKLOADS[args.workload]
@@ -122,7 +129,7 @@ def main():
         r.set_partition(rank, world)
         dev_in = torch.from_numpy(tris).to("cuda")  # resident in HBM before timing
         mesh = r.bind_mesh_device(dev_in.data_ptr(), ntris, fr.VS_CLIP, keepalive=dev_in)
-        gather = BandGather(H, W, torch.float32, "cuda", rank, world) if world > 1 else None
+        gather = BandGather(H, W, torch.float32, "cuda", rank, world) if dist is not None else None
         final = None
 
         def step():
@@ -166,7 +173,7 @@ def main():
 
         # multi-GPU image check on rank 0: gathered image == what a single full render would hold
         image_ok = None
-        if world > 1 and rank == 0:
+        if gather is not None and rank == 0:
             # every pixel of the gathered depth image must come from its owner's render (clear value 0 or a
             # positive 1/w): finite and non-negative everywhere, and not all background
             img = final[:H]
