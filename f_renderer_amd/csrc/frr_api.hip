@@ -14,10 +14,10 @@ using namespace frr;
 
 namespace {
 
-enum KernelId { KID_CLEAR, KID_GEOM_COUNT, KID_SCAN_BLOCKS, KID_GEOM_EMIT, KID_GEOM_EMIT_CLIP, KID_BIN_COUNT,
+enum KernelId { KID_CLEAR, KID_GEOM_COUNT, KID_SCAN_BLOCKS, KID_GEOM_EMIT, KID_BIN_COUNT,
                 KID_TILE_SCAN, KID_BIN_FILL, KID_RASTER, KID_BIN_COLSCAN, KID_COUNT };
 const char *const kKernelNames[KID_COUNT] = {"k_clear", "k_geom_count", "k_scan_blocks", "k_geom_emit",
-                                             "k_geom_emit_clip", "k_bin_count", "k_tile_scan", "k_bin_fill",
+                                             "k_bin_count", "k_tile_scan", "k_bin_fill",
                                              "k_raster", "k_bin_colscan"};
 
 struct Mesh {
@@ -48,7 +48,6 @@ struct frr_ctx {
     unsigned long long *lb_status = nullptr; size_t lb_status_cap = 0;
     int bin_g = 0;             // FRR_BIN_G: override the number of binning chunks (dev)
     bool geom_twopass = true;  // default; FRR_GEOM=lookback selects the single-pass look-back kernel (slower on MI355X: 79 vs 57 us at 1M tris)
-    uint2 *clip_list = nullptr; size_t clip_cap = 0;
     RasterRec *recs = nullptr; size_t setup_cap = 0; size_t setup_hint = 0;
     float *vary = nullptr; size_t vary_cap = 0; // floats
     uint2 *pbox = nullptr; size_t pbox_cap = 0;
@@ -192,9 +191,6 @@ template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks
           hipLaunchKernelGGL(k_geom_begin, dim3(std::min<uint32_t>((nblocks + 255) / 256, 64)), dim3(256), 0, c->stream, g.status, nblocks, g.ntris, g.cnt); }
         { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, true>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
     }
-    { ProfScope p(c, KID_GEOM_EMIT_CLIP);
-      uint32_t gb = (uint32_t)std::min<uint64_t>((g.ntris + 63) / 64, 256); // one wave per CU; scratch-heavy
-      hipLaunchKernelGGL(k_geom_emit_clip<VS>, dim3(gb), dim3(64), 0, c->stream, g, c->duni); }
 }
 
 template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uint32_t grid)
@@ -292,7 +288,7 @@ void frr_destroy(frr_ctx *c)
     prof_collect(c);
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
-    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->lb_status, c->clip_list, c->recs, c->vary, c->pbox,
+    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->lb_status, c->recs, c->vary, c->pbox,
                     c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bins2, c->bin_matrix};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -432,14 +428,13 @@ int frr_geometry(frr_ctx *c, int mesh, uint64_t *ntris_setup)
     int rc;
     if ((rc = ensure(c, c->block_sums, c->block_sums_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
     if ((rc = ensure(c, c->lb_status, c->lb_status_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
-    if ((rc = ensure(c, c->clip_list, c->clip_cap, (size_t)nt + 1)) != FRR_OK) return rc;
     if ((rc = ensure(c, c->recs, c->setup_cap, (size_t)cap)) != FRR_OK) return rc;
     if ((rc = ensure(c, c->pbox, c->pbox_cap, c->setup_cap)) != FRR_OK) return rc;
     if (K > 0 && (rc = ensure(c, c->vary, c->vary_cap, (size_t)c->setup_cap * 3 * 8 /* K <= 8 in the shader table */)) != FRR_OK) return rc;
     GeomArgs g;
     g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
     g.cap = (uint32_t)std::min<size_t>(c->setup_cap, K > 0 ? c->vary_cap / (3 * (size_t)K) : c->setup_cap);
-    g.block_sums = c->block_sums; g.status = c->lb_status; g.clip_list = c->clip_list; g.clip_cap = (uint32_t)c->clip_cap;
+    g.block_sums = c->block_sums; g.status = c->lb_status;
     g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;
     if (nt == 0) {
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, 0u, g.cap, 0u, g.cnt);

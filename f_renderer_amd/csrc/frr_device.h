@@ -26,9 +26,9 @@ static_assert(sizeof(RasterRec) == 64, "one cache line per triangle");
 
 struct Counters {
     uint32_t n_setup;       // setup triangles of the current draw
-    uint32_t n_clip;        // entries in the clip work list of the current draw
+    uint32_t reserved0;
     uint32_t tri_base;      // emission index of this draw's first triangle within the frame
-    uint32_t overflow;      // bit0 setup capacity, bit1 bin capacity, bit2 clip list
+    uint32_t overflow;      // bit0 setup capacity, bit1 bin capacity
     uint64_t bin_total;     // (triangle,tile) pairs of the current draw
     uint64_t frag_covered;  // since last clear
     uint64_t frag_nan;
@@ -60,8 +60,6 @@ struct GeomArgs {
     uint32_t cap;           // setup capacity (triangles)
     uint32_t *block_sums;   // [nblocks], exclusive-scanned in place (two-pass path)
     unsigned long long *status; // [nblocks] look-back status words (single-pass path)
-    uint2 *clip_list;       // (input index, output offset)
-    uint32_t clip_cap;
     RasterRec *recs;
     float *vary;
     uint2 *pbox;            // per setup triangle: pixel bbox of spi as 4 x i16 (minx|miny<<16, maxx|maxy<<16)

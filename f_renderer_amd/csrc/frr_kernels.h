@@ -1,7 +1,7 @@
 // frr_kernels.h -- the gfx950 kernels of the rasterization path (wave64, LDS-tiled).
 //
-// Frame = clear -> per draw { geometry: count, scan, emit, emit_clip ; binning: count, scan, fill ;
-// raster+resolve per 32x32 screen tile }.  See DESIGN.md for the roofline of each kernel.
+// Frame = clear -> per draw { geometry: count, scan, emit (clipping inside, wave-cooperative) ;
+// binning: LDS multi-split count, column scan, CSR scan, scatter ; raster+resolve per 32x32 tile }.  See DESIGN.md for the roofline of each kernel.
 #pragma once
 #include "frr_device.h"
 #include <type_traits>
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_clear(uint4 *__restrict__ color, uint4 
         ids[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        cnt->n_setup = 0; cnt->n_clip = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
+        cnt->n_setup = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
         cnt->frag_covered = 0; cnt->frag_nan = 0; cnt->tris_in = 0; cnt->bin_entries_frame = 0; cnt->draws = 0;
         for (int k = 0; k < 8; ++k) cnt->dbg[k] = 0;
     }
@@ -114,7 +114,6 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *__restrict__ sum
         cnt->need_setup = total;
         if (total > cap) { cnt->overflow |= 1u; total = 0; }
         cnt->n_setup = total;
-        cnt->n_clip = 0;
         cnt->tris_in += ntris;
         cnt->draws += 1;
     }
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *__restrict__ sum
 // K1c geometry emit, unclipped fast path: renderer.rs:113-148 (VS, reject, classify),
 // :180-218 (centroid + stable angle sort of 3), :220-235 (divide, viewport, snap), :237-243,
 // then the per-triangle prologue of rasterization (:300-320) so the record is ready to scan.
-// Clipped triangles only reserve their output range and go to the clip work list.
+// Clipped triangles are collected per block and handled by clip_triangle_wave (one wave each).
 // ---------------------------------------------------------------------------------------------
 // Single-pass variant (LOOKBACK): the block offsets come from a decoupled look-back scan over
 // 64-bit status words {flag:2, value:62} (flag 1 = block aggregate, 2 = inclusive prefix), so the
@@ -137,7 +136,6 @@ __global__ __launch_bounds__(256) void k_geom_begin(unsigned long long *status, 
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nblocks; i += gridDim.x * 256u) status[i] = 0ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cnt->tri_base += cnt->n_setup; // previous draw's triangles precede this draw's in the frame
-        cnt->n_clip = 0;
         cnt->ticket = 0;
         cnt->tris_in += ntris;
         cnt->draws += 1;
@@ -174,13 +172,116 @@ __device__ __forceinline__ uint32_t lookback_exclusive(unsigned long long *st, u
     return excl;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Clipped triangles: the reference's quirky clipper (renderer.rs:150-171: one intersection per
+// (edge, plane) with differing in/out flags, outside vertices kept), centroid + stable angle sort of
+// up to 21 vertices (:180-218), fan emission (:245-266) -- done by ONE WAVE per triangle:
+// lanes 0..17 = the 3 pairs x 6 planes in the reference's loop order, lanes 18..20 = the originals,
+// so "list order" is simply lane order among the kept lanes.
+// ---------------------------------------------------------------------------------------------
+constexpr int CLIP_MAXV = 21;
+
+template <int VS>
+__device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevUniforms &u, uint32_t t, uint32_t off, int lane,
+                                                   float (*s_xy)[2], int32_t *s_key, float (*s_v)[7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)])
+{
+    constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K, KS = K > 0 ? K : 1;
+    float pos[3][4], ctx[3][KS];
+    const float *in = g.in + (size_t)t * (3 * NF);
+#pragma unroll
+    for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
+    // this lane's vertex
+    float p[4], c[KS];
+    bool keep;
+    if (lane < 18) {
+        const int pi = lane / 6, plane = lane - pi * 6;      // pairs (0,1),(0,2),(1,2)
+        float a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] = pi == 2 ? pos[1][k] : pos[0][k]; b[k] = pi == 0 ? pos[1][k] : pos[2][k]; }
+        const bool differ = ((inside_bits(a) ^ inside_bits(b)) >> plane) & 1u;
+        const float r = intersect_ratio(plane, a, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = a[k] + r * (b[k] - a[k]);                       // :89
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float ca = pi == 2 ? ctx[1][k] : ctx[0][k], cb = pi == 0 ? ctx[1][k] : ctx[2][k];
+            c[k] = ca + (cb - ca) * r;                                                     // :91
+        }
+        keep = differ && fabsf(p[3]) > CLIP_EPSILON;                                       // :161-166
+    } else {
+        const int v = lane - 18;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = v == 0 ? pos[0][k] : (v == 1 ? pos[1][k] : pos[2][k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) c[k] = v == 0 ? ctx[0][k] : (v == 1 ? ctx[1][k] : ctx[2][k]);
+        keep = lane < CLIP_MAXV;                                                           // :171
+    }
+    const unsigned long long km = __ballot(keep);
+    const int n = __popcll(km);
+    const int li = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (keep) { s_xy[li][0] = p[0]; s_xy[li][1] = p[1]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float cx = 0.0f, cy = 0.0f;                                                            // :180-187, list order
+    for (int k = 0; k < n; ++k) { cx += s_xy[k][0]; cy += s_xy[k][1]; }
+    const float inv_n = 1.0f / (float)n;
+    cx *= inv_n; cy *= inv_n;
+    const int32_t key = total_order_key(sort_angle(p[1] - cy, p[0] - cx));
+    if (keep) s_key[li] = key;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int rank = 0;                                                                          // stable sort position (:205-218)
+    for (int k = 0; k < n; ++k) { const int32_t ok = s_key[k]; rank += (ok < key || (ok == key && k < li)) ? 1 : 0; }
+    const ScreenVtx sv = to_screen(p, (float)g.width, (float)g.height);                    // :220-235
+    if (keep) {
+        float *o = s_v[rank];
+        o[0] = sv.rhw; o[1] = sv.ndcx; o[2] = sv.ndcy; o[3] = sv.sx; o[4] = sv.sy; o[5] = __int_as_float(sv.ix); o[6] = __int_as_float(sv.iy);
+#pragma unroll
+        for (int k = 0; k < K; ++k) o[7 + k] = c[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // fan (:237-266): n == 3 -> [0,1,2]; else [0,last-1,last] for last = n-1 .. 4, then [0,2,3], [0,1,2]
+    if (lane < n - 2) {
+        const int q = lane;
+        int i1, i2;
+        if (q < n - 4) { i2 = n - 1 - q; i1 = i2 - 1; } else if (q == n - 4) { i1 = 2; i2 = 3; } else { i1 = 1; i2 = 2; }
+        const float *v0 = s_v[0];
+        const float nz = (s_v[i1][1] - v0[1]) * (s_v[i2][2] - v0[2]) - (s_v[i2][1] - v0[1]) * (s_v[i1][2] - v0[2]); // :300-305
+        const bool swap = nz > 0.0f;
+        const float *v1 = s_v[swap ? i2 : i1], *v2 = s_v[swap ? i1 : i2];                  // :309-312
+        const int p0x = __float_as_int(v0[5]), p0y = __float_as_int(v0[6]), p1x = __float_as_int(v1[5]), p1y = __float_as_int(v1[6]);
+        const int p2x = __float_as_int(v2[5]), p2y = __float_as_int(v2[6]);
+        uint32_t flags = swap ? 1u : 0u;
+        flags |= is_top_left(p0x, p0y, p1x, p1y) ? 0u : 2u;                                // :318-320
+        flags |= is_top_left(p1x, p1y, p2x, p2y) ? 0u : 4u;
+        flags |= is_top_left(p2x, p2y, p0x, p0y) ? 0u : 8u;
+        const uint32_t idx = off + (uint32_t)q;
+        g.pbox[idx] = pack_pbox(p0x, p0y, p1x, p1y, p2x, p2y);
+        uint4 *dst = reinterpret_cast<uint4 *>(g.recs + idx);
+        dst[0] = make_uint4((uint32_t)p0x, (uint32_t)p0y, (uint32_t)p1x, (uint32_t)p1y);
+        dst[1] = make_uint4((uint32_t)p2x, (uint32_t)p2y, f2u(v0[3]), f2u(v0[4]));
+        dst[2] = make_uint4(f2u(v1[3]), f2u(v1[4]), f2u(v2[3]), f2u(v2[4]));
+        dst[3] = make_uint4(f2u(v0[0]), f2u(v1[0]), f2u(v2[0]), flags);
+        if constexpr (K > 0) {
+            float *o = g.vary + (size_t)idx * (3 * K);
+#pragma unroll
+            for (int k = 0; k < K; ++k) { o[k] = v0[7 + k]; o[K + k] = v1[7 + k]; o[2 * K + k] = v2[7 + k]; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // staging is reused by the wave's next triangle
+}
+
 template <int VS, bool LOOKBACK>
 __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniforms u)
 {
     __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_bid, s_base;
+    __shared__ uint32_t s_bid, s_base, s_nclip;
+    __shared__ uint2 s_clist[GEOM_BLOCK];                 // (input index, output offset) of this block's clipped triangles
+    __shared__ float s_cxy[GEOM_BLOCK / 64][CLIP_MAXV][2]; // per wave: clip x,y in list order
+    __shared__ int32_t s_ckey[GEOM_BLOCK / 64][CLIP_MAXV];
+    __shared__ float s_cv[GEOM_BLOCK / 64][CLIP_MAXV][7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)];
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K;
     uint32_t bid = blockIdx.x;
+    if (threadIdx.x == 0) s_nclip = 0; // ordered before its first use by the barrier inside block_excl_scan256
     if constexpr (LOOKBACK) {
         if (threadIdx.x == 0) s_bid = atomicAdd(&g.cnt->ticket, 1u);
         __syncthreads();
@@ -214,17 +315,13 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
         }
         __syncthreads();
         off += s_base;
-        if (n == 0 || off + n > g.cap) return; // nothing to emit / capacity overflow (frame flagged invalid)
     } else {
         off += g.block_sums[blockIdx.x];
-        if (n == 0 || g.cnt->n_setup == 0) return; // n_setup == 0: nothing to emit or capacity overflow
     }
-    if (clipped) {
-        uint32_t slot = atomicAdd(&g.cnt->n_clip, 1u);
-        if (slot < g.clip_cap) g.clip_list[slot] = make_uint2(t, off);
-        else atomicOr(&g.cnt->overflow, 4u);
-        return;
-    }
+    // nothing to emit (None / dropped) or capacity overflow (the frame is flagged invalid)
+    const bool emit_ok = n != 0 && (LOOKBACK ? off + n <= g.cap : g.cnt->n_setup != 0u);
+    if (emit_ok && clipped) s_clist[atomicAdd(&s_nclip, 1u)] = make_uint2(t, off); // handled below, by a whole wave
+    if (emit_ok && !clipped) {
     // centroid (:180-187), n == 3
     float cx = 0.0f, cy = 0.0f;
 #pragma unroll
@@ -279,78 +376,14 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
 #pragma unroll
             for (int k = 0; k < K; ++k) o[s * K + k] = in_slot_f(s, ctx[0][k], ctx[1][k], ctx[2][k]);
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1d geometry emit, clipped slow path: the reference's quirky clipper reproduced as is
-// (renderer.rs:150-171: one intersection per (edge, plane) with differing in/out flags, outside
-// vertices kept), centroid + stable angle sort of up to 21 vertices (:180-218), fan (:245-266).
-// One lane per clipped triangle, grid-stride over the work list; vertex list in scratch.
-// ---------------------------------------------------------------------------------------------
-template <int VS>
-__global__ __launch_bounds__(64) void k_geom_emit_clip(GeomArgs g, DevUniforms u)
-{
-    constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K, KS = K > 0 ? K : 1;
-    const uint32_t nclip = min(g.cnt->n_clip, g.clip_cap);
-    for (uint32_t e = blockIdx.x * 64 + threadIdx.x; e < nclip; e += gridDim.x * 64) {
-        const uint2 item = g.clip_list[e];
-        const float *in = g.in + (size_t)item.x * (3 * NF);
-        float vpos[21][4];
-        float vctx[21][KS];
-        float pos[3][4], ctx[3][KS];
-#pragma unroll
-        for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
-        uint32_t inb[3] = {inside_bits(pos[0]), inside_bits(pos[1]), inside_bits(pos[2])};
-        int n = 0;
-        for (int i = 0; i < 3; ++i)
-            for (int j = i + 1; j < 3; ++j) {
-                uint32_t diff = inb[i] ^ inb[j];
-                for (int p = 0; p < 6; ++p)
-                    if (diff & (1u << p)) {
-                        float t = intersect_ratio(p, pos[i], pos[j]);
-                        float np[4];
-                        for (int k = 0; k < 4; ++k) np[k] = pos[i][k] + t * (pos[j][k] - pos[i][k]); // :89
-                        if (fabsf(np[3]) > CLIP_EPSILON) {                                          // :164
-                            for (int k = 0; k < 4; ++k) vpos[n][k] = np[k];
-                            for (int k = 0; k < K; ++k) vctx[n][k] = ctx[i][k] + (ctx[j][k] - ctx[i][k]) * t; // :91
-                            ++n;
-                        }
-                    }
-            }
-        for (int v = 0; v < 3; ++v) {                                                               // :171
-            for (int k = 0; k < 4; ++k) vpos[n][k] = pos[v][k];
-            for (int k = 0; k < K; ++k) vctx[n][k] = ctx[v][k];
-            ++n;
-        }
-        float cx = 0.0f, cy = 0.0f;                                                                 // :180-187
-        for (int i = 0; i < n; ++i) { cx += vpos[i][0]; cy += vpos[i][1]; }
-        float inv_n = 1.0f / (float)n;
-        cx *= inv_n; cy *= inv_n;
-        int32_t key[21];
-        int ord[21];
-        for (int i = 0; i < n; ++i) {
-            key[i] = total_order_key(sort_angle(vpos[i][1] - cy, vpos[i][0] - cx));
-            ord[i] = i;
-        }
-        for (int i = 1; i < n; ++i) { // stable insertion sort on (key, ord)
-            int32_t tk = key[i];
-            int to = ord[i];
-            int j = i - 1;
-            while (j >= 0 && key[j] > tk) { key[j + 1] = key[j]; ord[j + 1] = ord[j]; --j; }
-            key[j + 1] = tk; ord[j + 1] = to;
-        }
-        const float fw = (float)g.width, fh = (float)g.height;
-        auto emit = [&](uint32_t idx, int i0, int i1, int i2) {
-            const int a = ord[i0], b = ord[i1], c = ord[i2];
-            ScreenVtx sa = to_screen(vpos[a], fw, fh), sb = to_screen(vpos[b], fw, fh), sc = to_screen(vpos[c], fw, fh);
-            store_setup<K>(g.recs, g.vary, g.pbox, idx, sa, sb, sc, vctx[a], vctx[b], vctx[c]);
-        };
-        uint32_t idx = item.y;
-        if (n == 3) { emit(idx, 0, 1, 2); continue; }       // :237-243 (cannot happen for clipped, kept)
-        int last = n - 1;                                   // :245-266
-        while (last > 3) { emit(idx++, 0, last - 1, last); --last; }
-        emit(idx++, 0, 2, 3);
-        emit(idx++, 0, 1, 2);
+    } // fast path
+    __syncthreads();
+    // clipped triangles of this block: one wave per triangle, lanes = candidate vertices
+    const uint32_t nclip = s_nclip;
+    if (nclip) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (uint32_t e = (uint32_t)w; e < nclip; e += GEOM_BLOCK / 64)
+            clip_triangle_wave<VS>(g, u, s_clist[e].x, s_clist[e].y, lane, s_cxy[w], s_ckey[w], s_cv[w]);
     }
 }
 

@@ -270,7 +270,7 @@ class Renderer:
         self._check(self._lib.frr_event_elapsed_ms(self._ctx, a, b, C.byref(ms)))
         return float(ms.value)
 
-    KERNELS = ("k_clear", "k_geom_count", "k_scan_blocks", "k_geom_emit", "k_geom_emit_clip", "k_bin_count",
+    KERNELS = ("k_clear", "k_geom_count", "k_scan_blocks", "k_geom_emit", "k_bin_count",
                "k_tile_scan", "k_bin_fill", "k_raster", "k_bin_colscan")
 
     def profile_enable(self, on=True, kernels=None):
