@@ -412,7 +412,7 @@ int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
     return FRR_OK;
 }
 
-int frr_geometry(frr_ctx *c, int mesh, uint64_t *ntris_setup)
+static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filter, int32_t fy0, int32_t fy1)
 {
     if (!c || mesh < 0 || mesh >= (int)c->meshes.size() || !c->meshes[mesh].used) return fail(c, FRR_ERR_INVALID, "bad mesh id");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -434,6 +434,7 @@ int frr_geometry(frr_ctx *c, int mesh, uint64_t *ntris_setup)
     GeomArgs g;
     g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
     g.cap = (uint32_t)std::min<size_t>(c->setup_cap, K > 0 ? c->vary_cap / (3 * (size_t)K) : c->setup_cap);
+    g.part_rank = c->rank; g.part_world = filter ? c->world : 1; g.part_y0 = fy0; g.part_y1 = fy1;
     g.block_sums = c->block_sums; g.status = c->lb_status;
     g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;
     if (nt == 0) {
@@ -455,6 +456,8 @@ int frr_geometry(frr_ctx *c, int mesh, uint64_t *ntris_setup)
     }
     return FRR_OK;
 }
+
+int frr_geometry(frr_ctx *c, int mesh, uint64_t *ntris_setup) { return geometry_impl(c, mesh, ntris_setup, false, 0, 0); }
 
 int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1)
 {
@@ -527,7 +530,10 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
 
 int frr_draw(frr_ctx *c, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1)
 {
-    int rc = frr_geometry(c, mesh, nullptr);
+    // frr_draw knows the raster window, so a partitioned ctx can skip the setup records of triangles
+    // that touch none of its tile rows (frr_geometry alone cannot: the window comes later)
+    const bool filter = c && c->world > 1 && y0 <= y1;
+    int rc = geometry_impl(c, mesh, nullptr, filter, y0, y1);
     if (rc != FRR_OK) return rc;
     return frr_raster(c, ps_id, x0, x1, y0, y1);
 }

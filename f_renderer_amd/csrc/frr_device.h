@@ -58,6 +58,8 @@ struct GeomArgs {
     uint32_t ntris;
     uint32_t width, height; // viewport of renderer.rs:107-108
     uint32_t cap;           // setup capacity (triangles)
+    int32_t part_rank, part_world; // tile-row ownership filter (world == 1: none); only set by frr_draw,
+    int32_t part_y0, part_y1;      // which knows the raster window's height range
     uint32_t *block_sums;   // [nblocks], exclusive-scanned in place (two-pass path)
     unsigned long long *status; // [nblocks] look-back status words (single-pass path)
     RasterRec *recs;
@@ -86,6 +88,8 @@ struct RasterArgs {
     uint32_t *tri_id;
     Counters *cnt;
 };
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 // ---- glam pieces used by the shader table -------------------------------------
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)

@@ -322,6 +322,24 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
     const bool emit_ok = n != 0 && (LOOKBACK ? off + n <= g.cap : g.cnt->n_setup != 0u);
     if (emit_ok && clipped) s_clist[atomicAdd(&s_nclip, 1u)] = make_uint2(t, off); // handled below, by a whole wave
     if (emit_ok && !clipped) {
+    const float fw = (float)g.width, fh = (float)g.height;
+    const ScreenVtx s0 = to_screen(pos[0], fw, fh), s1 = to_screen(pos[1], fw, fh), s2 = to_screen(pos[2], fw, fh);
+    // Multi-GPU: a rank that owns none of the tile rows this triangle's bbox touches never reads its
+    // record; it only leaves an empty bbox for the binning passes (geometry is replicated, so this
+    // is what keeps the replicated part small).
+    bool owned = true;
+    if (g.part_world > 1) {
+        const int miny = clampi(min(s0.iy, min(s1.iy, s2.iy)), g.part_y0, g.part_y1);
+        const int maxy = clampi(max(s0.iy, max(s1.iy, s2.iy)), g.part_y0, g.part_y1);
+        owned = false;
+        if (maxy > miny) {
+            const int ty0 = (miny - g.part_y0) / TILE, ty1 = (maxy - 1 - g.part_y0) / TILE;
+            const int first = ty0 + ((g.part_rank - ty0 % g.part_world) + g.part_world) % g.part_world;
+            owned = first <= ty1;
+        }
+        if (!owned) g.pbox[off] = make_uint2(0u, 0u);
+    }
+    if (owned) {
     // centroid (:180-187), n == 3
     float cx = 0.0f, cy = 0.0f;
 #pragma unroll
@@ -335,8 +353,6 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
     int r0 = (key[1] < key[0]) + (key[2] < key[0]);
     int r1 = (key[0] <= key[1]) + (key[2] < key[1]);
     // (the third rank is implied by the other two)
-    const float fw = (float)g.width, fh = (float)g.height;
-    const ScreenVtx s0 = to_screen(pos[0], fw, fh), s1 = to_screen(pos[1], fw, fh), s2 = to_screen(pos[2], fw, fh);
     // Everything below is a permutation of the three vertices: sorted order, then the orientation
     // swap of renderer.rs:300-312.  It is written as scalar selects on the destination slot of each
     // input vertex (struct-valued selects end up as runtime-indexed scratch).
@@ -346,9 +362,8 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
     const float cx2 = by_rank(2, s0.ndcx, s1.ndcx, s2.ndcx), cy2 = by_rank(2, s0.ndcy, s1.ndcy, s2.ndcy);
     const float v01x = bx - ax, v01y = by - ay, v02x = cx2 - ax, v02y = cy2 - ay;
     const bool swap = (v01x * v02y - v02x * v01y) > 0.0f;                 // :300-309
-    const int r2 = 3 - r0 - r1;
     auto slot_of = [&](int r) { return r == 0 ? 0 : ((r == 1) != swap ? 1 : 2); };
-    const int d0 = slot_of(r0), d1 = slot_of(r1), d2 = slot_of(r2);      // destination slot of input vertex i
+    const int d0 = slot_of(r0), d1 = slot_of(r1);                        // destination slot of input vertex 0, 1 (2: the other)
     auto in_slot_f = [&](int s, float x0, float x1, float x2) { return d0 == s ? x0 : (d1 == s ? x1 : x2); };
     auto in_slot_i = [&](int s, int x0, int x1, int x2) { return d0 == s ? x0 : (d1 == s ? x1 : x2); };
     int px[3], py[3];
@@ -376,6 +391,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
 #pragma unroll
             for (int k = 0; k < K; ++k) o[s * K + k] = in_slot_f(s, ctx[0][k], ctx[1][k], ctx[2][k]);
     }
+    } // owned
     } // fast path
     __syncthreads();
     // clipped triangles of this block: one wave per triangle, lanes = candidate vertices
@@ -396,7 +412,6 @@ constexpr int BIN_COOP = 6;
 
 struct TileRange { int tx0, tx1, ty0, ty1; }; // inclusive-exclusive tile ranges (window-local)
 
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 __device__ __forceinline__ TileRange tiles_of_pbox(const RasterArgs &a, const uint2 b)
 {

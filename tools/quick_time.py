@@ -10,6 +10,9 @@ if len(sys.argv) > 1: W, H, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv
 tris = scenes.random_clip_triangles(n, W, H)
 r = fr.Renderer(W, H)
 m = r.upload_mesh(tris, fr.VS_CLIP)
+if os.environ.get('PART'):
+    rk, wd = map(int, os.environ['PART'].split(','))
+    r.set_partition(rk, wd)
 for _ in range(3):
     r.clear(); r.draw(m, fr.PS_DEPTH)
 r.sync()
