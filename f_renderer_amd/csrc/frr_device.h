@@ -81,7 +81,7 @@ struct RasterArgs {
     uint32_t *tile_offsets;           // [ntiles+1]
     uint32_t *tile_cursor;            // [ntiles]
     uint32_t *bins;
-    uint32_t *bins2;                  // same capacity; scratch for the tile kernel's near-first order
+    uint32_t *bins2;                  // 4 u32 per bin entry: the tile kernel's cull records {tri, zub, bbox} in near-first order
     uint32_t bin_cap;
     uint8_t *color;
     float *depth;

@@ -10,7 +10,7 @@
 //
 // Two coverage strategies produce the same fragment set {pixels passing renderer.rs:329-341}:
 //   k_raster       one triangle per wavefront, brute-force sweep of bbox-in-tile pixels (64/step);
-//   k_raster_span  a batch of triangles per wavefront: exact per-row spans from the integer edge
+//   k_raster_span  cull records -> survivors -> a batch of triangles per wavefront: exact per-row spans from the integer edge
 //                  functions, then fragments packed 64 per step (no lane idles on uncovered bbox
 //                  pixels).  Triangles whose coordinates could overflow i32 in the span algebra
 //                  (|spi| > 8192, only the clipper's far-away vertices) take the brute-force sweep,
@@ -181,6 +181,10 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
 // ---------------------------------------------------------------------------------------------
 constexpr int SPAN_SAFE = 8192; // |spi| and window coordinates up to this keep every edge value < 2^30
 constexpr int SPAN_BATCH = 32;  // triangles per wavefront batch (staging sized for 8 workgroups per CU)
+#ifndef FRR_SPAN_CULL
+#define FRR_SPAN_CULL 32
+#endif
+constexpr int SPAN_CULL = FRR_SPAN_CULL; // bin entries culled per step (<= 64): smaller = fresher z minima, more steps
 
 // wave64 inclusive prefix sum on the DPP network (row_shr within 16-lane rows, then row broadcasts)
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x)
@@ -295,6 +299,7 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
     __shared__ unsigned long long s_hrow[4][B / 2]; // heads of (triangle -> rows): B*32 bits
     __shared__ unsigned long long s_hfrag[4][32];  // heads of (span -> fragments): 64*32 bits
     __shared__ uint32_t s_q[4][64];                // compacted span descriptors
+    __shared__ uint32_t s_aq[4][64];               // per wave: triangles that survived phase 1a
     __shared__ __attribute__((aligned(16))) uint32_t s_hz[HZ_SIZE]; // hierarchical z (see hiz_rebuild)
     __shared__ uint32_t s_next;
     __shared__ uint32_t s_bkt[64];
@@ -308,24 +313,33 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // ---- near-first order: a coarse bucket sort of this tile's bin by the triangles' depth upper
-    // bound (64 buckets: 4 exponent bits + 2 mantissa bits of max|rhw_i|).  Processing order does not
-    // change any output (the z resolution is order independent); it only makes early-z reject more.
-    const uint32_t *__restrict__ bin_order = a.bins;
-    if (!COUNT && c.end - c.beg > 2u * B) {
-        uint32_t ct[4], cb[4];
-        auto bucket_of = [&](uint32_t t) {
-            const uint4 q3 = reinterpret_cast<const uint4 *>(a.recs + t)[3];
-            const float m = fmaxf(fmaxf(fabsf(u2f(q3.x)), fabsf(u2f(q3.y))), fabsf(u2f(q3.z)));
-            return 63u - ((f2u(m) >> 21) & 63u);
+    // ---- pre-pass: every bin entry becomes a 16-byte cull record {triangle, zkey of an upper bound of
+    // its rhw, pixel bbox}, written in NEAR-FIRST order (a 64-bucket sort on 4 exponent + 2 mantissa
+    // bits of the bound) into this tile's own range of `ents`.  The order cannot change any output (the
+    // z resolution is order independent); it only makes the hierarchical early-z below reject more.
+    // Upper bound: rhw = (r0*a + r1*b) + r2*c with a+b+c = 1 up to a few roundings, so
+    // |rhw| <= max|r_i| * (1 + 2^-18); NaN vertices disable it.
+    uint4 *__restrict__ ents = reinterpret_cast<uint4 *>(a.bins2);
+    {
+        const bool sorted = !COUNT && c.end - c.beg > 2u * B;
+        auto make_ent = [&](uint32_t t) {
+            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + t);
+            const uint4 q0 = rp[0], q1 = rp[1], q3 = rp[3];
+            const float ar0 = fabsf(u2f(q3.x)), ar1 = fabsf(u2f(q3.y)), ar2 = fabsf(u2f(q3.z));
+            const float ub = fmaxf(fmaxf(ar0, ar1), ar2) * 1.000003814697265625f;
+            const uint32_t zub = (ar0 == ar0 && ar1 == ar1 && ar2 == ar2) ? zkey(ub) : 0xFFFFFFFFu;
+            const uint2 pb = pack_pbox((int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y);
+            return make_uint4(t, zub, pb.x, pb.y);
         };
+        auto bucket_of = [&](const uint4 &e) { return sorted ? 63u - ((e.y >> 21) & 63u) : 0u; };
+        uint4 ce[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t e = c.beg + threadIdx.x + 256u * k;
-            ct[k] = 0; cb[k] = 0;
-            if (e < c.end) { ct[k] = a.bins[e]; cb[k] = bucket_of(ct[k]); atomicAdd(&s_bkt[cb[k]], 1u); }
+            ce[k] = make_uint4(0, 0, 0, 0);
+            if (e < c.end) { ce[k] = make_ent(a.bins[e]); atomicAdd(&s_bkt[bucket_of(ce[k])], 1u); }
         }
-        for (uint32_t e = c.beg + threadIdx.x + 1024u; e < c.end; e += 256u) atomicAdd(&s_bkt[bucket_of(a.bins[e])], 1u);
+        for (uint32_t e = c.beg + threadIdx.x + 1024u; e < c.end; e += 256u) atomicAdd(&s_bkt[bucket_of(make_ent(a.bins[e]))], 1u);
         __syncthreads();
         if (w == 0) {
             const uint32_t x = s_bkt[lane];
@@ -336,16 +350,15 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t e = c.beg + threadIdx.x + 256u * k;
-            if (e < c.end) a.bins2[atomicAdd(&s_bkt[cb[k]], 1u)] = ct[k];
+            if (e < c.end) ents[atomicAdd(&s_bkt[bucket_of(ce[k])], 1u)] = ce[k];
         }
         for (uint32_t e = c.beg + threadIdx.x + 1024u; e < c.end; e += 256u) {
-            const uint32_t t = a.bins[e];
-            a.bins2[atomicAdd(&s_bkt[bucket_of(t)], 1u)] = t;
+            const uint4 en = make_ent(a.bins[e]);
+            ents[atomicAdd(&s_bkt[bucket_of(en)], 1u)] = en;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        bin_order = a.bins2;
     }
 
     const uint32_t le_lo = lane < 32 ? (2u << lane) - 1u : 0xFFFFFFFFu;
@@ -355,19 +368,71 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
     uint32_t d_tri = 0, d_alive = 0, d_rows = 0, d_spans = 0, d_spans_live = 0, d_frags = 0, d_fwin = 0, d_rwin = 0;
 #endif
 
+    int aq_n = 0;            // survivors waiting in this wave's queue (wave-uniform)
+    bool input_done = false;
     for (;;) {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&s_next, 1u);
-        b = __builtin_amdgcn_readfirstlane(b);
-        const uint32_t e0 = c.beg + b * (uint32_t)B;
-        if (e0 >= c.end) break;
-        const int nb = (int)min((uint32_t)B, c.end - e0);
-        hiz_rebuild(s_key, s_hz, lane);
-        wave_lds_fence();
+        // ---- phase 1a: lane = bin entry, 64 per step.  bbox-in-tile + whole-triangle early-z on the
+        // 16-byte cull records only; survivors are queued, nothing else is touched for the rest. ----
+        if (!input_done && aq_n == 0) { // survivors are processed before more entries are culled (fresh z minima)
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(&s_next, 1u);
+            b = __builtin_amdgcn_readfirstlane(b);
+            const uint32_t e0 = c.beg + b * (uint32_t)SPAN_CULL;
+            if (e0 >= c.end) {
+                input_done = true;
+            } else {
+                const int nb64 = (int)min((uint32_t)SPAN_CULL, c.end - e0);
+                hiz_rebuild(s_key, s_hz, lane);
+                wave_lds_fence();
+                const bool valid = lane < nb64;
+                const uint4 en = valid ? ents[e0 + lane] : make_uint4(0, 0, 0, 0);
+                const int mnx = (int)(short)(en.z & 0xFFFFu), mny = (int)(short)(en.z >> 16);
+                const int mxx = (int)(short)(en.w & 0xFFFFu), mxy = (int)(short)(en.w >> 16);
+                const int bx0 = max(clampi(mnx, a.x0, a.x1), c.ax0), bx1 = min(clampi(mxx, a.x0, a.x1), c.ax0 + c.tw);
+                const int by0 = max(clampi(mny, a.y0, a.y1), c.ay0), by1 = min(clampi(mxy, a.y0, a.y1), c.ay0 + c.th);
+                const bool nonempty = valid && bx1 > bx0 && by1 > by0;
+                // (the bbox saturates at +-32767, so out-of-range vertices show up here too)
+                const int amax = max(max(abs(mnx), abs(mxx)), max(abs(mny), abs(mxy)));
+                const bool safe = nonempty && win_safe && amax <= SPAN_SAFE;
+                bool alive = safe;
+                if (!COUNT && safe) {
+                    // against the 8x8 block minima when the bbox touches <= 2x2 blocks, else against the
+                    // 16x16 quad minima (a tile has 2x2 quads, so this always applies)
+                    const int gx0 = (bx0 - c.ax0) >> 3, gx1 = (bx1 - 1 - c.ax0) >> 3, gy0 = (by0 - c.ay0) >> 3, gy1 = (by1 - 1 - c.ay0) >> 3;
+                    const bool small = gx1 - gx0 <= 1 && gy1 - gy0 <= 1;
+                    const uint32_t *lv = s_hz + (small ? HZ_BLK : HZ_QUAD);
+                    const int sh = small ? 0 : 1, st = small ? 4 : 2;
+                    const int ix0 = gx0 >> sh, ix1 = gx1 >> sh, iy0 = gy0 >> sh, iy1 = gy1 >> sh;
+                    const uint32_t hm = min(min(lv[iy0 * st + ix0], lv[iy0 * st + ix1]), min(lv[iy1 * st + ix0], lv[iy1 * st + ix1]));
+                    alive = !(en.y < hm);
+                }
+#ifdef FRR_DEBUG_COUNTERS
+                d_tri += __popcll(__ballot(nonempty)); d_alive += __popcll(__ballot(alive));
+#endif
+                // triangles outside the span algebra's safe range: exact brute-force sweep, right away
+                unsigned long long um = __ballot(nonempty && !safe);
+                while (um) {
+                    const int src = __builtin_ctzll(um);
+                    um &= um - 1;
+                    const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)en.x, src);
+                    uint32_t ncv = 0;
+                    sweep_triangle(a, c, tu, lane, s_key, ncv, n_nan);
+                    n_cov += ncv;
+                }
+                const unsigned long long am = __ballot(alive);
+                const int arank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+                if (alive) s_aq[w][aq_n + arank] = en.x;
+                aq_n += __popcll(am);
+                wave_lds_fence();
+            }
+        }
+        if (aq_n == 0) { if (input_done) break; continue; }
 
-        // ---- phase 1: lane = triangle.  Record -> bbox-in-tile, edge coefficients, staging ----
+        // ---- phase 1b: lane = surviving triangle.  Record gather, edge coefficients, staging ----
+        const int nb = min(aq_n, B);
+        aq_n -= nb;
         const bool valid = lane < nb;
-        const uint32_t t = valid ? bin_order[e0 + lane] : 0u;
+        const uint32_t t = valid ? s_aq[w][aq_n + lane] : 0u;
         const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + t);
         uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
         if (valid) { q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3]; }
@@ -377,31 +442,11 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
         bx0 = max(bx0, c.ax0); bx1 = min(bx1, c.ax0 + c.tw);
         by0 = max(by0, c.ay0); by1 = min(by1, c.ay0 + c.th);
         const int bw = bx1 - bx0, bh = by1 - by0;
-        const int amax = max(max(max(abs(p0x), abs(p0y)), max(abs(p1x), abs(p1y))), max(abs(p2x), abs(p2y)));
-        const bool nonempty = valid && bw > 0 && bh > 0;
-        const bool safe = nonempty && win_safe && amax <= SPAN_SAFE;
-        const unsigned long long unsafe_mask = __ballot(nonempty && !safe);
-        // Upper bound on any fragment's rhw: rhw = (r0*a + r1*b) + r2*c with a+b+c = 1 up to a few
-        // roundings, so |rhw| <= max|r_i| * (1 + 2^-18).  NaN vertices disable the bound.
         const float ar0 = fabsf(u2f(q3.x)), ar1 = fabsf(u2f(q3.y)), ar2 = fabsf(u2f(q3.z));
         const float ub = fmaxf(fmaxf(ar0, ar1), ar2) * 1.000003814697265625f;
         const uint32_t zub = (ar0 == ar0 && ar1 == ar1 && ar2 == ar2) ? zkey(ub) : 0xFFFFFFFFu;
-        bool alive = safe;
-        if (!COUNT && safe) {
-            // whole-triangle early-z: against the 8x8 block minima when the bbox touches <= 2x2 blocks,
-            // else against the 16x16 quad minima (a tile has 2x2 quads, so this always applies)
-            const int gx0 = (bx0 - c.ax0) >> 3, gx1 = (bx1 - 1 - c.ax0) >> 3, gy0 = (by0 - c.ay0) >> 3, gy1 = (by1 - 1 - c.ay0) >> 3;
-            const bool small = gx1 - gx0 <= 1 && gy1 - gy0 <= 1;
-            const uint32_t *lv = s_hz + (small ? HZ_BLK : HZ_QUAD);
-            const int sh = small ? 0 : 1, st = small ? 4 : 2;
-            const int ix0 = gx0 >> sh, ix1 = gx1 >> sh, iy0 = gy0 >> sh, iy1 = gy1 >> sh;
-            const uint32_t hm = min(min(lv[iy0 * st + ix0], lv[iy0 * st + ix1]), min(lv[iy1 * st + ix0], lv[iy1 * st + ix1]));
-            alive = !(zub < hm);
-        }
+        const bool alive = valid; // every queued triangle is non-empty in this tile and in the safe range
         const uint32_t rows = alive ? (uint32_t)bh : 0u;
-#ifdef FRR_DEBUG_COUNTERS
-        d_tri += __popcll(__ballot(nonempty)); d_alive += __popcll(__ballot(alive));
-#endif
         if (alive) {
             // wrapping arithmetic spelled in u32; for `safe` triangles nothing wraps
             const uint32_t A01 = 0u - (uint32_t)(p1y - p0y), B01 = (uint32_t)(p1x - p0x);
@@ -522,16 +567,6 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
             wave_lds_fence(); // s_q / s_hfrag are rewritten by the next row window
         }
 
-        // ---- triangles outside the span algebra's safe range: exact brute-force sweep ----
-        unsigned long long um = unsafe_mask;
-        while (um) {
-            const int src = __builtin_ctzll(um);
-            um &= um - 1;
-            const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)t, src);
-            uint32_t ncv = 0;
-            sweep_triangle(a, c, tu, lane, s_key, ncv, n_nan);
-            n_cov += ncv;
-        }
         wave_lds_fence(); // staging is rewritten by the next batch
     }
     if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
