@@ -47,6 +47,8 @@ struct frr_ctx {
     uint32_t *block_sums = nullptr; size_t block_sums_cap = 0;
     unsigned long long *lb_status = nullptr; size_t lb_status_cap = 0;
     int bin_g = 0;             // FRR_BIN_G: override the number of binning chunks (dev)
+    bool bin_atomics = false;  // FRR_BIN=atomics: force the global-atomic binning fallback (tests)
+    size_t bin_cap_init = 0;   // FRR_BIN_CAP: initial bin capacity in entries (tests of the overflow path)
     bool geom_twopass = true;  // default; FRR_GEOM=lookback selects the single-pass look-back kernel (slower on MI355X: 79 vs 57 us at 1M tris)
     RasterRec *recs = nullptr; size_t setup_cap = 0; size_t setup_hint = 0;
     float *vary = nullptr; size_t vary_cap = 0; // floats
@@ -251,6 +253,8 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     { const char *e = getenv("FRR_RASTER"); c->raster_sweep = e && strcmp(e, "sweep") == 0; }
     { const char *e = getenv("FRR_GEOM"); c->geom_twopass = !(e && strcmp(e, "lookback") == 0); }
     { const char *e = getenv("FRR_BIN_G"); c->bin_g = e ? atoi(e) : 0; }
+    { const char *e = getenv("FRR_BIN"); c->bin_atomics = e && strcmp(e, "atomics") == 0; }
+    { const char *e = getenv("FRR_BIN_CAP"); c->bin_cap_init = e ? (size_t)atoll(e) : 0; }
     if (stream) c->stream = (hipStream_t)stream;
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FRR_ERR_HIP; } c->own_stream = true; }
     const size_t npx = (size_t)width * height;
@@ -485,13 +489,14 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     int rc;
     if (!c->bins) {
         size_t want = std::max<size_t>((size_t)c->geom_ntris * 8 + 4 * (size_t)c->max_tiles, (size_t)1 << 22);
+        if (c->bin_cap_init) want = c->bin_cap_init;
         if ((rc = ensure(c, c->bins, c->bin_cap, want)) != FRR_OK) return rc;
         if ((rc = ensure(c, c->bins2, c->bin2_cap, want * 4)) != FRR_OK) return rc;
     }
     a.bins2 = c->bins2;
     a.bins = c->bins; a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xFFFFFFFFu);
     a.color = c->color; a.depth = c->depth; a.tri_id = c->tri_id; a.cnt = c->cnt;
-    if (ntiles <= BIN_LDS_MAX_TILES) {
+    if (ntiles <= BIN_LDS_MAX_TILES && !c->bin_atomics) {
         // LDS multi-split (no global atomics): G chunk workgroups, ~3K triangles each
         uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + 3071) / 3072, 1), BIN_MAX_G);
         if (c->bin_g > 0) G = (uint32_t)std::min(c->bin_g, BIN_MAX_G);

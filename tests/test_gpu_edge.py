@@ -1,0 +1,164 @@
+"""Edge cases and the less-travelled code paths of the HIP library, all against the oracle:
+capacity overflow + re-issue, global-atomic binning fallback, device-bound meshes and targets,
+empty / degenerate inputs, non-square textures, several texture slots."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_depth(oracle, tris, W, H):
+    f = oracle.Frame(W, H)
+    f.clear()
+    f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
+    return f
+
+
+def test_bin_capacity_overflow_is_reported_then_recovers(oracle, monkeypatch):
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    monkeypatch.setenv("FRR_BIN_CAP", "2000")            # far too small on purpose
+    W, H = 256, 192
+    tris = scenes.random_clip_triangles(4000, W, H, seed=3, spread=1.0)
+    f = _oracle_depth(oracle, tris, W, H)
+    r = fr.Renderer(W, H)
+    m = r.upload_mesh(tris, fr.VS_CLIP)
+    r.clear()
+    r.draw(m, fr.PS_DEPTH)
+    with pytest.raises(fr.FrrError) as e:
+        r.readback()
+    assert e.value.code == fr.FRR_ERR_CAPACITY            # frame flagged invalid, capacity grown
+    r.clear()
+    r.draw(m, fr.PS_DEPTH)                                # re-issue
+    _, d, t = r.readback()
+    np.testing.assert_array_equal(t, f.tri_id)
+    np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+
+
+def test_global_atomic_binning_fallback(oracle, monkeypatch):
+    """The path used when a frame has more tiles than fit LDS counters (> 36,864 tiles)."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    monkeypatch.setenv("FRR_BIN", "atomics")
+    W, H = 300, 200
+    tris = scenes.random_clip_triangles(9000, W, H, seed=4, spread=1.25, w_jitter=0.6)   # incl. huge fans
+    f = _oracle_depth(oracle, tris, W, H)
+    if f.counters.frag_nan:
+        pytest.skip("NaN rhw")
+    r = fr.Renderer(W, H)
+    r.clear()
+    r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
+    _, d, t = r.readback()
+    np.testing.assert_array_equal(t, f.tri_id)
+    np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+    assert r.stats()["frag_covered"] == f.counters.frag_covered
+
+
+def test_device_bound_mesh_and_targets(oracle):
+    """frr_mesh_bind_device / frr_bind_targets with torch-owned HBM (the bench.py plumbing)."""
+    import torch
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H = 320, 224
+    tris = scenes.random_clip_triangles(5000, W, H, seed=5)
+    f = _oracle_depth(oracle, tris, W, H)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        r = fr.Renderer(W, H, stream=s.cuda_stream)
+        color = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        depth = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+        ids = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        r.bind_targets(color.data_ptr(), depth.data_ptr(), ids.data_ptr())
+        assert r.target_ptrs() == (color.data_ptr(), depth.data_ptr(), ids.data_ptr())
+        dev = torch.from_numpy(tris).cuda()
+        m = r.bind_mesh_device(dev.data_ptr(), tris.shape[0], fr.VS_CLIP, keepalive=dev)
+        r.clear()
+        r.draw(m, fr.PS_DEPTH)
+        r.sync()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(depth.cpu().numpy().reshape(-1).view(np.uint32), f.depth.view(np.uint32))
+    np.testing.assert_array_equal(ids.cpu().numpy().reshape(-1).view(np.uint32), f.tri_id)
+
+
+def test_empty_and_degenerate_inputs(oracle):
+    import f_renderer_amd as fr
+    W, H = 64, 64
+    r = fr.Renderer(W, H)
+    f = oracle.Frame(W, H)
+    r.clear()
+    f.clear()
+    empty = r.upload_mesh(np.zeros((0, 3, 4), np.float32), fr.VS_CLIP)
+    r.draw(empty, fr.PS_DEPTH)                                           # no triangles at all
+    degen = np.array([
+        [[0.1, 0.1, 0.5, 1], [0.1, 0.1, 0.5, 1], [0.1, 0.1, 0.5, 1]],    # all three vertices equal
+        [[-0.5, 0.0, 0.5, 1], [0.0, 0.0, 0.5, 1], [0.5, 0.0, 0.5, 1]],   # collinear
+        [[0.2, 0.2, 0.5, 0], [0.3, 0.2, 0.5, 1], [0.2, 0.3, 0.5, 1]],    # w == 0 -> dropped
+        [[-0.9, -0.9, 0.5, 1], [0.9, -0.9, 0.5, 1], [0.0, 0.9, 0.5, 1]], # a real one
+        [[-0.9, -0.9, 0.5, 1], [0.9, -0.9, 0.5, 1], [0.0, 0.9, 0.5, 1]], # its duplicate: later wins ties
+    ], np.float32)
+    r.set_uniforms(flat_color=(0.25, 0.5, 0.75, 1.0))
+    r.draw(r.upload_mesh(degen, fr.VS_CLIP), fr.PS_FLAT)
+    f.draw(degen, oracle.VS_CLIP, oracle.PS_FLAT, oracle.make_uniforms(flat_color=(0.25, 0.5, 0.75, 1.0)))
+    c, d, t = r.readback()
+    np.testing.assert_array_equal(t, f.tri_id)
+    np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+    np.testing.assert_array_equal(c, f.color)
+    st = r.stats()
+    assert st["tris_in"] == 5 and st["tris_setup"] == f.counters.tris_setup == 4 and st["draws"] == 2
+
+
+def test_non_square_texture_and_slots(oracle):
+    """height > width is legal (sample_2d clamps y with width, renderer.rs:523); height < width is
+    rejected because the reference would index out of bounds; uniforms.texture_slot = `place`."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H = 200, 120
+    mesh = scenes.displaced_sphere(n=20)
+    tall = scenes.checker_texture(64, 8)
+    tall = np.concatenate([tall, tall[::-1]], axis=0)                   # 128 x 64
+    other = scenes.checker_texture(32, 4)
+    eye, at, up, fovy, aspect, zn, zf = scenes.demo_camera(W, H)
+    r = fr.Renderer(W, H)
+    with pytest.raises(fr.FrrError) as e:
+        r.set_texture(0, np.zeros((16, 32, 4), np.uint8))
+    assert e.value.code == fr.FRR_ERR_UNSUPPORTED
+    r.set_texture(0, other)
+    r.set_texture(2, tall)
+    r.set_uniforms(view=fr.set_look_at(eye, at, up), proj=fr.set_perspective(fovy, aspect, zn, zf), view_pos=eye, texture_slot=2)
+    r.clear()
+    r.draw(r.upload_mesh(mesh, fr.VS_PHONG), fr.PS_PHONG)
+    f = oracle.Frame(W, H)
+    f.clear()
+    u = oracle.make_uniforms(view=oracle.set_look_at(eye, at, up), proj=oracle.set_perspective(fovy, aspect, zn, zf),
+                             view_pos=eye, tex=oracle.Texture(tall))
+    f.draw(mesh, oracle.VS_PHONG, oracle.PS_PHONG, u)
+    c, d, _ = r.readback()
+    np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+    np.testing.assert_array_equal(c, f.color)
+    r.set_uniforms(texture_slot=3)                                      # nothing uploaded there
+    with pytest.raises(fr.FrrError):
+        r.draw(r.upload_mesh(mesh, fr.VS_PHONG), fr.PS_PHONG)
+
+
+def test_partition_with_window(oracle):
+    """tile-row partition combined with a sub-window (tile rows are window-local)."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H, G = 256, 192, 2
+    tris = scenes.random_clip_triangles(5000, W, H, seed=8, spread=1.1)
+    wr, hr = (16, 240), (10, 170)
+    f = oracle.Frame(W, H)
+    f.clear()
+    f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms(), window=(wr[0], wr[1], hr[0], hr[1]))
+    acc = np.full(W * H, 0xFFFFFFFF, np.uint32)
+    for rank in range(G):
+        r = fr.Renderer(W, H)
+        r.set_partition(rank, G)
+        r.clear()
+        r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH, wr, hr)
+        _, _, t = r.readback()
+        drawn = t != 0xFFFFFFFF
+        assert not (drawn & (acc != 0xFFFFFFFF)).any()                  # ranks never touch each other's pixels
+        acc[drawn] = t[drawn]
+        r.close()
+    np.testing.assert_array_equal(acc, f.tri_id)
