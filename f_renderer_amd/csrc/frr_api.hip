@@ -688,6 +688,35 @@ void frr_set_perspective(float fovy, float aspect, float zn, float zf, float m[1
 // ---- debug hooks ------------------------------------------------------------------------------
 float frr_host_atan2f(float y, float x) { return fd_atan2f(y, x); }
 
+int frr_debug_mvp(frr_ctx *c, int mesh, int use_mfma, float *clip_out, float *ms_out)
+{
+    if (!c || mesh < 0 || mesh >= (int)c->meshes.size() || !c->meshes[mesh].used || !clip_out) return fail(c, FRR_ERR_INVALID, "bad arguments");
+    const Mesh &m = c->meshes[mesh];
+    if (m.vs != FRR_VS_PHONG && m.vs != FRR_VS_GOURAUD) return fail(c, FRR_ERR_INVALID, "needs a pos3/uv2/normal3 mesh");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t nverts = (uint32_t)(m.ntris * 3);
+    float4 *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)nverts * 16 + 16) != hipSuccess) return fail(c, FRR_ERR_NOMEM, "hipMalloc");
+    const dim3 grid((nverts + 63) / 64), block(64);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int it = 0; it < 3; ++it) { // last iteration is the timed one
+        (void)hipEventRecord(e0, c->stream);
+        if (use_mfma) hipLaunchKernelGGL(k_debug_mvp_mfma, grid, block, 0, c->stream, m.dev, nverts, 8, c->duni, d);
+        else hipLaunchKernelGGL(k_debug_mvp_exact, grid, block, 0, c->stream, m.dev, nverts, 8, c->duni, d);
+        (void)hipEventRecord(e1, c->stream);
+    }
+    hipError_t e = hipMemcpyAsync(clip_out, d, (size_t)nverts * 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms_out) *ms_out = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, FRR_ERR_HIP, hipGetErrorString(e));
+    return FRR_OK;
+}
+
 int frr_debug_gather_calib(frr_ctx *c, uint32_t log2_records)
 {
     if (!c || log2_records < 10 || log2_records > 24) return FRR_ERR_INVALID;

@@ -606,6 +606,40 @@ __global__ __launch_bounds__(256) void k_bin_colscan(uint32_t *__restrict__ M, u
 namespace frr {
 
 // ---- debug --------------------------------------------------------------------------------
+// MFMA experiment (north_star: "MFMA used only for the batched 4x4 MVP x vertex-block contraction").
+// clip[4][16 vertices] = MVP[4x4] * P[4x16] with v_mfma_f32_16x16x4_f32: A = MVP in rows 0..3 of a 16x4
+// tile, B = (x,y,z,1) of 16 vertices; lane j < 16 receives vertex j's clip xyzw in its 4 accumulators.
+// The MFMA is an fmaf chain over k (one rounding per step); glam's Mat4*Vec4 rounds every product and
+// every sum, so the results differ in the last bits -- measured by tests/test_gpu_mfma.py, which is
+// why the parity path keeps the VALU form (k_debug_mvp_exact == run_vs<FRR_VS_PHONG>).
+typedef float frr_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void k_debug_mvp_mfma(const float *__restrict__ in, uint32_t nverts, int nf, DevUniforms u, float4 *out)
+{
+    const int lane = threadIdx.x;
+    const uint32_t v = blockIdx.x * 64u + lane;
+    float px = 0.0f, py = 0.0f, pz = 0.0f;
+    if (v < nverts) { px = in[(size_t)v * nf]; py = in[(size_t)v * nf + 1]; pz = in[(size_t)v * nf + 2]; }
+    const int r = lane & 15, k = lane >> 4;
+    const float a = r < 4 ? u.mvp[k * 4 + r] : 0.0f;                 // A[row r][k] = MVP(r, k), column-major storage
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int src = 16 * g + r;
+        const float bx = __shfl(px, src), by = __shfl(py, src), bz = __shfl(pz, src);
+        const float b = k == 0 ? bx : (k == 1 ? by : (k == 2 ? bz : 1.0f)); // B[k][col r]
+        frr_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        const uint32_t vo = blockIdx.x * 64u + 16u * g + lane;
+        if (lane < 16 && vo < nverts) out[vo] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+__global__ __launch_bounds__(64) void k_debug_mvp_exact(const float *__restrict__ in, uint32_t nverts, int nf, DevUniforms u, float4 *out)
+{
+    const uint32_t v = blockIdx.x * 64u + threadIdx.x;
+    if (v >= nverts) return;
+    float o[4];
+    mat4_mul_vec4(u.mvp, in[(size_t)v * nf], in[(size_t)v * nf + 1], in[(size_t)v * nf + 2], 1.0f, o);
+    out[v] = make_float4(o[0], o[1], o[2], o[3]);
+}
 // PMC calibration: every lane gathers one distinct 64-byte record (4 x dwordx4, the tile kernel's
 // phase-1 access pattern) from a table larger than the Infinity Cache; true bytes = n * 64.
 __global__ __launch_bounds__(256) void k_debug_gather(const uint4 *__restrict__ table, uint32_t n_mask, uint32_t *out)

@@ -179,6 +179,10 @@ void frr_set_perspective(float fovy, float aspect, float zn, float zf, float m[1
 int frr_debug_atan2f(frr_ctx *ctx, const float *y, const float *x, float *out, uint64_t n);
 /* the same source compiled for the host, to pin the port against glibc without a GPU */
 float frr_host_atan2f(float y, float x);
+/* MVP x vertex contraction of a pos3/uv2/normal3 mesh with the current uniforms: clip xyzw per vertex
+ * (ntris*3*4 floats) by the exact VALU form (use_mfma = 0, glam's association) or by
+ * v_mfma_f32_16x16x4_f32 (use_mfma = 1, an fmaf chain: NOT bit-identical); *ms = kernel time. */
+int frr_debug_mvp(frr_ctx *ctx, int mesh, int use_mfma, float *clip_out, float *ms);
 /* PMC calibration: gathers 2^log2_records distinct 64-byte records (true bytes = 64 << log2_records) */
 int frr_debug_gather_calib(frr_ctx *ctx, uint32_t log2_records);
 /* device wave64 inclusive prefix sum (DPP) of 64 values, for tests */
