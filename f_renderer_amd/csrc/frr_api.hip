@@ -49,6 +49,7 @@ struct frr_ctx {
     int bin_g = 0;             // FRR_BIN_G: override the number of binning chunks (dev)
     bool bin_atomics = false;  // FRR_BIN=atomics: force the global-atomic binning fallback (tests)
     size_t bin_cap_init = 0;   // FRR_BIN_CAP: initial bin capacity in entries (tests of the overflow path)
+    bool geom_force_scan = false; // FRR_GEOM=scan: always launch k_scan_blocks (the path used beyond 8192 blocks)
     bool geom_twopass = true;  // default; FRR_GEOM=lookback selects the single-pass look-back kernel (slower on MI355X: 79 vs 57 us at 1M tris)
     RasterRec *recs = nullptr; size_t setup_cap = 0; size_t setup_hint = 0;
     float *vary = nullptr; size_t vary_cap = 0; // floats
@@ -68,6 +69,7 @@ struct frr_ctx {
     uint64_t geom_ntris = 0;
     int rank = 0, world = 1;
     bool count_frags = true;   // exact covered-fragment statistic (disables whole-triangle early-z)
+    int raster_nw = 0;         // FRR_RASTER_NW: force 4 / 8 / 16 waves per tile workgroup (dev)
     bool raster_sweep = false; // FRR_RASTER=sweep: brute-force tile kernel instead of the span kernel
     hipEvent_t ev[16] = {};
     bool ev_set[16] = {};
@@ -185,13 +187,18 @@ int check_frame_counters(frr_ctx *c, Counters *host)
 template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks)
 {
     if (c->geom_twopass) {
+        g.selfsum = nblocks <= 8192 && !c->geom_force_scan; // each emit block then sums <= 8192 block counts itself
         { ProfScope p(c, KID_GEOM_COUNT); hipLaunchKernelGGL(k_geom_count<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
-        { ProfScope p(c, KID_SCAN_BLOCKS); hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, nblocks, g.cap, g.ntris, g.cnt); }
-        { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, false>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
+        if (g.selfsum) {
+            { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 2>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
+        } else {
+            { ProfScope p(c, KID_SCAN_BLOCKS); hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, nblocks, g.cap, g.ntris, g.cnt); }
+            { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 0>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
+        }
     } else {
         { ProfScope p(c, KID_SCAN_BLOCKS);
           hipLaunchKernelGGL(k_geom_begin, dim3(std::min<uint32_t>((nblocks + 255) / 256, 64)), dim3(256), 0, c->stream, g.status, nblocks, g.ntris, g.cnt); }
-        { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, true>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
+        { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 1>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
     }
 }
 
@@ -203,8 +210,21 @@ template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uin
     } else {
         // the span algebra needs every coordinate it touches within +-SPAN_SAFE (no i32 wrap)
         const int win_safe = a.x0 >= -SPAN_SAFE && a.y0 >= -SPAN_SAFE && a.x1 <= SPAN_SAFE && a.y1 <= SPAN_SAFE;
-        if (c->count_frags) hipLaunchKernelGGL((k_raster_span<K, PS, true>), dim3(grid), dim3(256), 0, c->stream, a, c->duni, win_safe);
-        else hipLaunchKernelGGL((k_raster_span<K, PS, false>), dim3(grid), dim3(256), 0, c->stream, a, c->duni, win_safe);
+        // waves per tile: 4 fills the chip when there are >= ~1024 tiles; fewer tiles (a partitioned rank,
+        // small windows) get 8 or 16 waves each so that the per-tile chain is shorter
+        int nw = grid >= 1024 ? 4 : (grid >= 512 ? 8 : 16);
+        if (c->raster_nw) nw = c->raster_nw;
+        auto go = [&](auto count_tag, auto nw_tag) {
+            constexpr bool CNT = decltype(count_tag)::value;
+            constexpr int NWV = decltype(nw_tag)::value;
+            hipLaunchKernelGGL((k_raster_span<K, PS, CNT, NWV>), dim3(grid), dim3(NWV * 64), 0, c->stream, a, c->duni, win_safe);
+        };
+        auto go_nw = [&](auto count_tag) {
+            if (nw == 4) go(count_tag, std::integral_constant<int, 4>{});
+            else if (nw == 8) go(count_tag, std::integral_constant<int, 8>{});
+            else go(count_tag, std::integral_constant<int, 16>{});
+        };
+        if (c->count_frags) go_nw(std::true_type{}); else go_nw(std::false_type{});
     }
 }
 
@@ -251,7 +271,8 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     frr_ctx *c = new frr_ctx();
     c->device = device; c->W = width; c->H = height;
     { const char *e = getenv("FRR_RASTER"); c->raster_sweep = e && strcmp(e, "sweep") == 0; }
-    { const char *e = getenv("FRR_GEOM"); c->geom_twopass = !(e && strcmp(e, "lookback") == 0); }
+    { const char *e = getenv("FRR_RASTER_NW"); const int v = e ? atoi(e) : 0; c->raster_nw = (v == 4 || v == 8 || v == 16) ? v : 0; }
+    { const char *e = getenv("FRR_GEOM"); c->geom_twopass = !(e && strcmp(e, "lookback") == 0); c->geom_force_scan = e && strcmp(e, "scan") == 0; }
     { const char *e = getenv("FRR_BIN_G"); c->bin_g = e ? atoi(e) : 0; }
     { const char *e = getenv("FRR_BIN"); c->bin_atomics = e && strcmp(e, "atomics") == 0; }
     { const char *e = getenv("FRR_BIN_CAP"); c->bin_cap_init = e ? (size_t)atoll(e) : 0; }
@@ -438,6 +459,7 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     GeomArgs g;
     g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
     g.cap = (uint32_t)std::min<size_t>(c->setup_cap, K > 0 ? c->vary_cap / (3 * (size_t)K) : c->setup_cap);
+    g.selfsum = 0;
     g.part_rank = c->rank; g.part_world = filter ? c->world : 1; g.part_y0 = fy0; g.part_y1 = fy1;
     g.block_sums = c->block_sums; g.status = c->lb_status;
     g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;

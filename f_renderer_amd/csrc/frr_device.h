@@ -58,6 +58,7 @@ struct GeomArgs {
     uint32_t ntris;
     uint32_t width, height; // viewport of renderer.rs:107-108
     uint32_t cap;           // setup capacity (triangles)
+    int32_t selfsum;        // emit blocks sum the block counts themselves (no k_scan_blocks launch)
     int32_t part_rank, part_world; // tile-row ownership filter (world == 1: none); only set by frr_draw,
     int32_t part_y0, part_y1;      // which knows the raster window's height range
     uint32_t *block_sums;   // [nblocks], exclusive-scanned in place (two-pass path)

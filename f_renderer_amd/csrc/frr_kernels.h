@@ -82,6 +82,11 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_count(GeomArgs g, DevUnifor
     uint32_t total;
     block_excl_scan256(n, s_w, total);
     if (threadIdx.x == 0) g.block_sums[blockIdx.x] = total;
+    if (g.selfsum && blockIdx.x == 0 && threadIdx.x == 0) { // per-draw bookkeeping k_scan_blocks would do
+        g.cnt->tri_base += g.cnt->n_setup;                  // previous draw's triangles precede this draw's
+        g.cnt->tris_in += g.ntris;
+        g.cnt->draws += 1;
+    }
 }
 
 // K1b: exclusive scan of the block sums (single workgroup), publishes n_setup, advances tri_base.
@@ -270,7 +275,9 @@ __device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevU
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // staging is reused by the wave's next triangle
 }
 
-template <int VS, bool LOOKBACK>
+// MODE 0: block_sums were exclusive-scanned by k_scan_blocks; MODE 1 (LOOKBACK): single pass, see above;
+// MODE 2: every block sums block_sums[0 .. b) itself (<= 8192 blocks: cheaper than a scan launch).
+template <int VS, int MODE>
 __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniforms u)
 {
     __shared__ uint32_t s_w[4];
@@ -280,6 +287,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
     __shared__ int32_t s_ckey[GEOM_BLOCK / 64][CLIP_MAXV];
     __shared__ float s_cv[GEOM_BLOCK / 64][CLIP_MAXV][7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)];
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K;
+    constexpr bool LOOKBACK = MODE == 1;
     uint32_t bid = blockIdx.x;
     if (threadIdx.x == 0) s_nclip = 0; // ordered before its first use by the barrier inside block_excl_scan256
     if constexpr (LOOKBACK) {
@@ -315,11 +323,26 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
         }
         __syncthreads();
         off += s_base;
+    } else if constexpr (MODE == 2) {
+        uint32_t part = 0;
+        for (uint32_t i = threadIdx.x; i < bid; i += GEOM_BLOCK) part += g.block_sums[i];
+        const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(part), 63);
+        __syncthreads();                       // s_w was read by block_excl_scan256 above
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = wsum;
+        __syncthreads();
+        const uint32_t excl = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        off += excl;
+        if (threadIdx.x == 0 && bid == gridDim.x - 1) { // the last block knows the grand total
+            const uint32_t all = excl + total;
+            g.cnt->need_setup = all;
+            if (all > g.cap) atomicOr(&g.cnt->overflow, 1u);
+            g.cnt->n_setup = all > g.cap ? 0u : all;
+        }
     } else {
         off += g.block_sums[blockIdx.x];
     }
     // nothing to emit (None / dropped) or capacity overflow (the frame is flagged invalid)
-    const bool emit_ok = n != 0 && (LOOKBACK ? off + n <= g.cap : g.cnt->n_setup != 0u);
+    const bool emit_ok = n != 0 && (MODE != 0 ? off + n <= g.cap : g.cnt->n_setup != 0u);
     if (emit_ok && clipped) s_clist[atomicAdd(&s_nclip, 1u)] = make_uint2(t, off); // handled below, by a whole wave
     if (emit_ok && !clipped) {
     const float fw = (float)g.width, fh = (float)g.height;

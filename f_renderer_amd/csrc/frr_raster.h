@@ -55,7 +55,7 @@ __device__ __forceinline__ TileCtx tile_ctx(const RasterArgs &a)
 __device__ __forceinline__ void tile_load_keys(const RasterArgs &a, const TileCtx &c, unsigned long long *s_key,
                                                unsigned long long oob = 0ull)
 {
-    for (int i = threadIdx.x; i < TILE_PX; i += 256) {
+    for (int i = threadIdx.x; i < TILE_PX; i += (int)blockDim.x) {
         const int x = i & (TILE - 1), y = i >> 5;
         unsigned long long k = oob;
         if (x < c.tw && y < c.th) k = (unsigned long long)zkey(a.depth[(size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x)]) << 32;
@@ -69,7 +69,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
                                              const unsigned long long *s_key)
 {
     const uint32_t tri_base = a.cnt->tri_base;
-    for (int i = threadIdx.x; i < TILE_PX; i += 256) {
+    for (int i = threadIdx.x; i < TILE_PX; i += (int)blockDim.x) {
         const int x = i & (TILE - 1), y = i >> 5;
         if (x >= c.tw || y >= c.th) continue;
         const uint32_t id = (uint32_t)s_key[i];
@@ -287,19 +287,21 @@ __device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uin
     }
 }
 
-template <int K, int PS, bool COUNT>
-__global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u, int win_safe)
+// NW = waves per tile workgroup: 4 when there are enough tiles to fill the chip (8 workgroups per CU),
+// 8 or 16 when a partitioned (multi-GPU) rank owns few tiles, so that a tile's bin is shared by more waves.
+template <int K, int PS, bool COUNT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUniforms u, int win_safe)
 {
     constexpr int B = SPAN_BATCH;
     __shared__ unsigned long long s_key[TILE_PX];
-    __shared__ TriI s_ti[4][B];
-    __shared__ float4 s_fa[4][B];                  // s0x s0y s1x s1y
-    __shared__ float4 s_fb[4][B];                  // s2x s2y rhw0 rhw1
-    __shared__ float2 s_fc[4][B];                  // rhw2, bit pattern of (triangle index + 1)
-    __shared__ unsigned long long s_hrow[4][B / 2]; // heads of (triangle -> rows): B*32 bits
-    __shared__ unsigned long long s_hfrag[4][32];  // heads of (span -> fragments): 64*32 bits
-    __shared__ uint32_t s_q[4][64];                // compacted span descriptors
-    __shared__ uint32_t s_aq[4][64];               // per wave: triangles that survived phase 1a
+    __shared__ TriI s_ti[NW][B];
+    __shared__ float4 s_fa[NW][B];                  // s0x s0y s1x s1y
+    __shared__ float4 s_fb[NW][B];                  // s2x s2y rhw0 rhw1
+    __shared__ float2 s_fc[NW][B];                  // rhw2, bit pattern of (triangle index + 1)
+    __shared__ unsigned long long s_hrow[NW][B / 2]; // heads of (triangle -> rows): B*32 bits
+    __shared__ unsigned long long s_hfrag[NW][32];  // heads of (span -> fragments): 64*32 bits
+    __shared__ uint32_t s_q[NW][64];                // compacted span descriptors
+    __shared__ uint32_t s_aq[NW][64];               // per wave: triangles that survived phase 1a
     __shared__ __attribute__((aligned(16))) uint32_t s_hz[HZ_SIZE]; // hierarchical z (see hiz_rebuild)
     __shared__ uint32_t s_next;
     __shared__ uint32_t s_bkt[64];
@@ -335,11 +337,11 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
         uint4 ce[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t e = c.beg + threadIdx.x + 256u * k;
+            const uint32_t e = c.beg + threadIdx.x + (uint32_t)(NW * 64) * k;
             ce[k] = make_uint4(0, 0, 0, 0);
             if (e < c.end) { ce[k] = make_ent(a.bins[e]); atomicAdd(&s_bkt[bucket_of(ce[k])], 1u); }
         }
-        for (uint32_t e = c.beg + threadIdx.x + 1024u; e < c.end; e += 256u) atomicAdd(&s_bkt[bucket_of(make_ent(a.bins[e]))], 1u);
+        for (uint32_t e = c.beg + threadIdx.x + 4u * NW * 64; e < c.end; e += NW * 64) atomicAdd(&s_bkt[bucket_of(make_ent(a.bins[e]))], 1u);
         __syncthreads();
         if (w == 0) {
             const uint32_t x = s_bkt[lane];
@@ -349,10 +351,10 @@ __global__ __launch_bounds__(256) void k_raster_span(RasterArgs a, DevUniforms u
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t e = c.beg + threadIdx.x + 256u * k;
+            const uint32_t e = c.beg + threadIdx.x + (uint32_t)(NW * 64) * k;
             if (e < c.end) ents[atomicAdd(&s_bkt[bucket_of(ce[k])], 1u)] = ce[k];
         }
-        for (uint32_t e = c.beg + threadIdx.x + 1024u; e < c.end; e += 256u) {
+        for (uint32_t e = c.beg + threadIdx.x + 4u * NW * 64; e < c.end; e += NW * 64) {
             const uint4 en = make_ent(a.bins[e]);
             ents[atomicAdd(&s_bkt[bucket_of(en)], 1u)] = en;
         }

@@ -6,12 +6,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("geom", ["lookback", "twopass"])
+@pytest.mark.parametrize("geom", ["lookback", "scan", "default"])
 def test_geometry_paths_agree_with_oracle(oracle, geom, monkeypatch):
     import f_renderer_amd as fr
     from f_renderer_amd import scenes
-    if geom == "lookback":
-        monkeypatch.setenv("FRR_GEOM", "lookback")
+    if geom != "default":
+        monkeypatch.setenv("FRR_GEOM", geom)
     W, H, n = 400, 300, 70000          # many 256-triangle blocks, dropped (w == 0) and clipped triangles
     tris = scenes.random_clip_triangles(n, W, H, seed=9, spread=1.2)
     tris[::97, 1, 3] = 0.0             # w == 0 on one vertex: triangle dropped (renderer.rs:117-119)
