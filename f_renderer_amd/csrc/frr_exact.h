@@ -161,10 +161,72 @@ FRR_HD float fd_atan2f(float y, float x)
     }
 }
 
+// Branch-free forms of the two functions above for the GPU (the three angle evaluations of a
+// triangle then interleave instead of serialising on divergent branches).  Every lane performs the
+// operations of its own fdlibm path on the selected operands, so the results are bit-identical to
+// fd_atanf / fd_atan2f (and to glibc): tools/atan2f_check.cpp sweeps all 2^32 atanf inputs and
+// 2*10^9 atan2f pairs for both forms.
+FRR_HD float fd_atanf_bf(float x)
+{
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
+                aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
+                aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f,
+                aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    const float ax = u2f((uint32_t)ix);
+    const int id = ix < 0x3ee00000 ? -1 : (ix < 0x3f300000 ? 0 : (ix < 0x3f980000 ? 1 : (ix < 0x401c0000 ? 2 : 3)));
+    const float num = id == 0 ? 2.0f * ax - 1.0f : (id == 1 ? ax - 1.0f : (id == 2 ? ax - 1.5f : -1.0f));
+    const float den = id == 0 ? 2.0f + ax : (id == 1 ? ax + 1.0f : (id == 2 ? 1.0f + 1.5f * ax : ax));
+    const float q = num / (id < 0 ? 1.0f : den);
+    const float xr = id < 0 ? x : q;
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    const float hi = id == 0 ? 4.6364760399e-01f : (id == 1 ? 7.8539812565e-01f : (id == 2 ? 9.8279368877e-01f : 1.5707962513e+00f));
+    const float lo = id == 0 ? 5.0121582440e-09f : (id == 1 ? 3.7748947079e-08f : (id == 2 ? 3.4473217170e-08f : 7.5497894159e-08f));
+    const float r_small = xr - xr * (s1 + s2);
+    const float r_big0 = hi - ((xr * (s1 + s2) - lo) - xr);
+    const float r_big = hx < 0 ? -r_big0 : r_big0;
+    float res = id < 0 ? r_small : r_big;
+    res = ix < 0x31000000 ? x : res;                                   // |x| < 2^-29
+    const float pio2 = 1.5707962513e+00f + 7.5497894159e-08f;
+    res = ix >= 0x4c000000 ? (ix > 0x7f800000 ? x + x : (hx > 0 ? pio2 : -pio2)) : res; // |x| >= 2^25, NaN
+    return res;
+}
+
+FRR_HD float fd_atan2f_bf(float y, float x)
+{
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f,
+                pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    const int32_t k = (iy - ix) >> 23;
+    const float za = fd_atanf_bf(u2f(f2u(y / x) & 0x7fffffffu));
+    const float z = k > 60 ? pi_o_2 + 0.5f * pi_lo : ((hx < 0 && k < -60) ? 0.0f : za);
+    float res = m == 0 ? z : (m == 1 ? u2f(f2u(z) ^ 0x80000000u) : (m == 2 ? pi - (z - pi_lo) : (z - pi_lo) - pi));
+    // the early returns of e_atan2f.c, lowest priority first (the x == 1.0 shortcut is value-neutral)
+    const float hpi = hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    res = iy == 0x7f800000 ? hpi : res;
+    const float xinf_yinf = m == 0 ? pi_o_4 + tiny : (m == 1 ? -pi_o_4 - tiny : (m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny));
+    const float xinf_yfin = m == 0 ? 0.0f : (m == 1 ? -0.0f : (m == 2 ? pi + tiny : -pi - tiny));
+    res = ix == 0x7f800000 ? (iy == 0x7f800000 ? xinf_yinf : xinf_yfin) : res;
+    res = ix == 0 ? hpi : res;
+    res = iy == 0 ? (m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny)) : res;
+    res = (ix > 0x7f800000 || iy > 0x7f800000) ? x + y : res;
+    return res;
+}
+
 // sort angle of renderer.rs:205-216: atan2 mapped to [0, 2pi)
 FRR_HD float sort_angle(float fy, float fx)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float a = fd_atan2f_bf(fy, fx);
+#else
     float a = fd_atan2f(fy, fx);
+#endif
     if (a < 0.0f) a += 3.14159274101257324f * 2.0f;
     return a;
 }
