@@ -369,12 +369,38 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
     for (int v = 0; v < 3; ++v) { cx += pos[v][0]; cy += pos[v][1]; }
     const float inv_n = 1.0f / 3.0f;
     cx *= inv_n; cy *= inv_n;
-    int32_t key[3];
+    // The sort of :205-218 only needs the ORDER of the three angles.  With d_v = vertex - centroid
+    // (the very f32 values atan2 would see), angle(a) < angle(b) in [0, 2pi) is decided by the
+    // half plane (sign of dy) and the sign of cross(a, b) -- exact whenever the true angles are
+    // farther apart, and farther from the 0 / pi axis, than SORT_EPS radians, which dwarfs the
+    // < 1e-6 error of the f32 atan2 + 2pi the reference compares.  Anything closer (or non-finite)
+    // takes the exact atan2f keys.
+    float dx[3], dy[3], d2[3];
 #pragma unroll
-    for (int v = 0; v < 3; ++v) key[v] = total_order_key(sort_angle(pos[v][1] - cy, pos[v][0] - cx));
+    for (int v = 0; v < 3; ++v) { dx[v] = pos[v][0] - cx; dy[v] = pos[v][1] - cy; d2[v] = dx[v] * dx[v] + dy[v] * dy[v]; }
+    constexpr float SORT_EPS2 = 1.0e-8f; // (1e-4 rad)^2
+    bool lt10, lt20, lt21, le01;
+    {
+        bool safe = true;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) safe = safe && (dy[v] * dy[v] > SORT_EPS2 * d2[v]) && (d2[v] < 1.0e30f);
+        auto less = [&](int a, int b) { // angle(a) < angle(b)
+            const float cr = dx[a] * dy[b] - dy[a] * dx[b];
+            const bool ha = dy[a] < 0.0f, hb = dy[b] < 0.0f;
+            safe = safe && (ha != hb || cr * cr > SORT_EPS2 * (d2[a] * d2[b]));
+            return ha != hb ? hb : cr > 0.0f;
+        };
+        lt10 = less(1, 0); lt20 = less(2, 0); lt21 = less(2, 1); le01 = !lt10;
+        if (!safe) {
+            int32_t key[3];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) key[v] = total_order_key(sort_angle(dy[v], dx[v]));
+            lt10 = key[1] < key[0]; lt20 = key[2] < key[0]; lt21 = key[2] < key[1]; le01 = key[0] <= key[1];
+        }
+    }
     // stable rank of each vertex (:205-218)
-    int r0 = (key[1] < key[0]) + (key[2] < key[0]);
-    int r1 = (key[0] <= key[1]) + (key[2] < key[1]);
+    int r0 = (int)lt10 + (int)lt20;
+    int r1 = (int)le01 + (int)lt21;
     // (the third rank is implied by the other two)
     // Everything below is a permutation of the three vertices: sorted order, then the orientation
     // swap of renderer.rs:300-312.  It is written as scalar selects on the destination slot of each

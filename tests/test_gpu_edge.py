@@ -162,3 +162,57 @@ def test_partition_with_window(oracle):
         acc[drawn] = t[drawn]
         r.close()
     np.testing.assert_array_equal(acc, f.tri_id)
+
+
+def test_vertex_sort_near_ties_and_axes(oracle):
+    """The device decides the centroid-angle order of an unclipped triangle with half-plane / cross
+    predicates and falls back to the exact atan2f keys near ties and near the 0 / pi axis
+    (k_geom_emit).  Adversarial triangles around those switches must still give the oracle's
+    setup records (vertex order, swap, snapped corners) bit for bit."""
+    import f_renderer_amd as fr
+    W, H = 256, 256
+    rng = np.random.default_rng(77)
+    tris = []
+    deltas = [0.0] + [s * 10.0 ** e for e in range(-8, -1) for s in (1.0, -1.0)]
+    for base in np.arange(0.0, 2.0 * np.pi, np.pi / 4.0):
+        for d0 in deltas:
+            for d1 in deltas:
+                c = rng.uniform(-0.5, 0.5, 2)
+                r0, r1 = rng.uniform(0.05, 0.3, 2)
+                a0, a1 = base + d0, base + d0 + d1
+                v0 = c + r0 * np.array([np.cos(a0), np.sin(a0)])
+                v1 = c + r1 * np.array([np.cos(a1), np.sin(a1)]) * (1.0 if rng.random() < 0.5 else -1.0)
+                v2 = 3.0 * c - v0 - v1                       # keeps the centroid (nearly) at c
+                tris.append([[v0[0], v0[1], 0.5, 1.0], [v1[0], v1[1], 0.5, 1.0], [v2[0], v2[1], 0.5, 1.0]])
+    # exact axis cases: a vertex exactly level with / above the centroid, repeated vertices, zero area
+    for k in range(200):
+        c = np.round(rng.uniform(-0.5, 0.5, 2) * 64.0) / 64.0
+        h = 2.0 ** -rng.integers(2, 6)
+        kind = k % 4
+        if kind == 0:
+            p = [c + [2 * h, 0], c + [-h, h], c + [-h, -h]]           # d0 on the +x axis exactly
+        elif kind == 1:
+            p = [c + [-2 * h, 0], c + [h, h], c + [h, -h]]            # d0 on the -x axis exactly
+        elif kind == 2:
+            p = [c + [h, 0], c + [-h, 0], c + [0, 0]]                 # collinear through the centroid
+        else:
+            p = [c + [h, h], c + [h, h], c + [-2 * h, -2 * h]]        # repeated vertex
+        tris.append([[q[0], q[1], 0.5, 1.0] for q in p])
+    tris = np.asarray(tris, dtype=np.float32)
+    perm = rng.permutation(len(tris))
+    tris = np.ascontiguousarray(tris[perm])
+    f = oracle.Frame(W, H)
+    f.clear()
+    setup = f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms(), keep_setup=True)
+    r = fr.Renderer(W, H)
+    r.clear()
+    r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
+    g = r.setup_triangles()
+    assert g.shape[0] == setup.shape[0]
+    np.testing.assert_array_equal(g["spi"], setup["spi"])
+    np.testing.assert_array_equal(g["spf"].view(np.uint32), setup["spf"].view(np.uint32))
+    np.testing.assert_array_equal(g["rhw"].view(np.uint32), setup["rhw"].view(np.uint32))
+    if not f.counters.frag_nan:
+        _, d, t = r.readback()
+        np.testing.assert_array_equal(t, f.tri_id)
+        np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
