@@ -53,12 +53,12 @@ struct frr_ctx {
     bool geom_twopass = true;  // default; FRR_GEOM=lookback selects the single-pass look-back kernel (slower on MI355X: 79 vs 57 us at 1M tris)
     RasterRec *recs = nullptr; size_t setup_cap = 0; size_t setup_hint = 0;
     float *vary = nullptr; size_t vary_cap = 0; // floats
-    uint2 *pbox = nullptr; size_t pbox_cap = 0;
+    uint4 *pbox = nullptr; size_t pbox_cap = 0;
     // binning workspace
     uint32_t *tile_counts = nullptr, *tile_offsets = nullptr, *tile_cursor = nullptr;
     uint32_t max_tiles = 0;
-    uint32_t *bins = nullptr; size_t bin_cap = 0;
-    uint32_t *bins2 = nullptr; size_t bin2_cap = 0; // 16-byte cull records in near-first order, written by the tile kernel (4 u32 per bin entry)
+    uint4 *bins = nullptr; size_t bin_cap = 0;   // 16-byte cull records, one per (triangle, tile) pair
+    uint4 *bins2 = nullptr; size_t bin2_cap = 0; // the same in near-first order per tile (tile kernel pre-pass)
     uint32_t *bin_matrix = nullptr; size_t bin_matrix_cap = 0; // [G][ntiles] per-chunk tile histograms
     bool lds_attr_set = false;
     std::vector<Mesh> meshes;
@@ -176,7 +176,7 @@ int check_frame_counters(frr_ctx *c, Counters *host)
         if (h.overflow & 2u) {
             size_t need = (size_t)(h.bin_total + h.bin_total / 4 + 1024);
             if (ensure(c, c->bins, c->bin_cap, need) != FRR_OK) return FRR_ERR_NOMEM;
-            if (ensure(c, c->bins2, c->bin2_cap, need * 4) != FRR_OK) return FRR_ERR_NOMEM;
+            if (ensure(c, c->bins2, c->bin2_cap, need) != FRR_OK) return FRR_ERR_NOMEM;
         }
         if (h.overflow & 1u) c->setup_hint = (size_t)h.need_setup + h.need_setup / 8 + 1024;
         return fail(c, FRR_ERR_CAPACITY, "device work list overflowed; capacity grown, re-issue the frame");
@@ -513,7 +513,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         size_t want = std::max<size_t>((size_t)c->geom_ntris * 8 + 4 * (size_t)c->max_tiles, (size_t)1 << 22);
         if (c->bin_cap_init) want = c->bin_cap_init;
         if ((rc = ensure(c, c->bins, c->bin_cap, want)) != FRR_OK) return rc;
-        if ((rc = ensure(c, c->bins2, c->bin2_cap, want * 4)) != FRR_OK) return rc;
+        if ((rc = ensure(c, c->bins2, c->bin2_cap, want)) != FRR_OK) return rc;
     }
     a.bins2 = c->bins2;
     a.bins = c->bins; a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xFFFFFFFFu);

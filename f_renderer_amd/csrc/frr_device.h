@@ -65,7 +65,7 @@ struct GeomArgs {
     unsigned long long *status; // [nblocks] look-back status words (single-pass path)
     RasterRec *recs;
     float *vary;
-    uint2 *pbox;            // per setup triangle: pixel bbox of spi as 4 x i16 (minx|miny<<16, maxx|maxy<<16)
+    uint4 *pbox;            // per setup triangle, the binning input: {minx|miny<<16, maxx|maxy<<16 (i16 pixel bbox of spi), zkey of an upper bound of |rhw|, 0}
     Counters *cnt;
 };
 
@@ -77,12 +77,12 @@ struct RasterArgs {
     int32_t rank, world;              // tile-row ownership (ty % world == rank)
     const RasterRec *recs;
     const float *vary;
-    const uint2 *pbox;
+    const uint4 *pbox;                // see GeomArgs::pbox
     uint32_t *tile_counts;            // [ntiles]
     uint32_t *tile_offsets;           // [ntiles+1]
     uint32_t *tile_cursor;            // [ntiles]
-    uint32_t *bins;
-    uint32_t *bins2;                  // 4 u32 per bin entry: the tile kernel's cull records {tri, zub, bbox} in near-first order
+    uint4 *bins;                      // one 16-byte cull record {tri, zub, bbox.x, bbox.y} per (triangle, tile) pair, CSR by tile
+    uint4 *bins2;                     // the same records in near-first order per tile (written by the tile kernel's pre-pass)
     uint32_t bin_cap;
     uint8_t *color;
     float *depth;
@@ -240,33 +240,13 @@ __device__ __forceinline__ uint2 pack_pbox(int x0, int y0, int x1, int y1, int x
     return make_uint2(s16(mnx) | (s16(mny) << 16), s16(mxx) | (s16(mxy) << 16));
 }
 
-// Orientation (renderer.rs:300-312) + top-left flags (:318-320) + record store, for one emitted
-// triangle whose vertices v0,v1,v2 are in emission order.
-template <int K>
-__device__ __forceinline__ void store_setup(RasterRec *__restrict__ recs, float *__restrict__ vary, uint2 *__restrict__ pbox, uint32_t idx,
-                                            const ScreenVtx &v0, ScreenVtx v1, ScreenVtx v2, const float *c0,
-                                            const float *c1, const float *c2)
+// Whole-triangle early-z bound: rhw = (r0*a + r1*b) + r2*c with a+b+c = 1 up to a few roundings, so
+// |rhw| <= max|r_i| * (1 + 2^-18); the z key of that bound, or all-ones (never culled) for NaN vertices.
+__device__ __forceinline__ uint32_t cull_zub(float r0, float r1, float r2)
 {
-    float v01x = v1.ndcx - v0.ndcx, v01y = v1.ndcy - v0.ndcy;
-    float v02x = v2.ndcx - v0.ndcx, v02y = v2.ndcy - v0.ndcy;
-    float nz = v01x * v02y - v02x * v01y;
-    bool swap = nz > 0.0f;
-    if (swap) { ScreenVtx t = v1; v1 = v2; v2 = t; const float *tc = c1; c1 = c2; c2 = tc; }
-    uint32_t flags = swap ? 1u : 0u;
-    flags |= is_top_left(v0.ix, v0.iy, v1.ix, v1.iy) ? 0u : 2u;
-    flags |= is_top_left(v1.ix, v1.iy, v2.ix, v2.iy) ? 0u : 4u;
-    flags |= is_top_left(v2.ix, v2.iy, v0.ix, v0.iy) ? 0u : 8u;
-    pbox[idx] = pack_pbox(v0.ix, v0.iy, v1.ix, v1.iy, v2.ix, v2.iy);
-    uint4 *dst = reinterpret_cast<uint4 *>(recs + idx);
-    dst[0] = make_uint4((uint32_t)v0.ix, (uint32_t)v0.iy, (uint32_t)v1.ix, (uint32_t)v1.iy);
-    dst[1] = make_uint4((uint32_t)v2.ix, (uint32_t)v2.iy, f2u(v0.sx), f2u(v0.sy));
-    dst[2] = make_uint4(f2u(v1.sx), f2u(v1.sy), f2u(v2.sx), f2u(v2.sy));
-    dst[3] = make_uint4(f2u(v0.rhw), f2u(v1.rhw), f2u(v2.rhw), flags);
-    if constexpr (K > 0) {
-        float *o = vary + (size_t)idx * (3 * K);
-#pragma unroll
-        for (int k = 0; k < K; ++k) { o[k] = c0[k]; o[K + k] = c1[k]; o[2 * K + k] = c2[k]; }
-    }
+    const float ar0 = fabsf(r0), ar1 = fabsf(r1), ar2 = fabsf(r2);
+    const float ub = fmaxf(fmaxf(ar0, ar1), ar2) * 1.000003814697265625f;
+    return (ar0 == ar0 && ar1 == ar1 && ar2 == ar2) ? zkey(ub) : 0xFFFFFFFFu;
 }
 
 // ---- fragment arithmetic (renderer.rs:343-360), shared by the coverage loop and the resolve --

@@ -260,7 +260,7 @@ __device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevU
         flags |= is_top_left(p1x, p1y, p2x, p2y) ? 0u : 4u;
         flags |= is_top_left(p2x, p2y, p0x, p0y) ? 0u : 8u;
         const uint32_t idx = off + (uint32_t)q;
-        g.pbox[idx] = pack_pbox(p0x, p0y, p1x, p1y, p2x, p2y);
+        { const uint2 pb = pack_pbox(p0x, p0y, p1x, p1y, p2x, p2y); g.pbox[idx] = make_uint4(pb.x, pb.y, cull_zub(v0[0], v1[0], v2[0]), 0u); }
         uint4 *dst = reinterpret_cast<uint4 *>(g.recs + idx);
         dst[0] = make_uint4((uint32_t)p0x, (uint32_t)p0y, (uint32_t)p1x, (uint32_t)p1y);
         dst[1] = make_uint4((uint32_t)p2x, (uint32_t)p2y, f2u(v0[3]), f2u(v0[4]));
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
             const int first = ty0 + ((g.part_rank - ty0 % g.part_world) + g.part_world) % g.part_world;
             owned = first <= ty1;
         }
-        if (!owned) g.pbox[off] = make_uint2(0u, 0u);
+        if (!owned) g.pbox[off] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (owned) {
     // centroid (:180-187), n == 3
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
     flags |= is_top_left(px[0], py[0], px[1], py[1]) ? 0u : 2u;           // :318-320
     flags |= is_top_left(px[1], py[1], px[2], py[2]) ? 0u : 4u;
     flags |= is_top_left(px[2], py[2], px[0], py[0]) ? 0u : 8u;
-    g.pbox[off] = pack_pbox(px[0], py[0], px[1], py[1], px[2], py[2]);
+    { const uint2 pb = pack_pbox(px[0], py[0], px[1], py[1], px[2], py[2]); g.pbox[off] = make_uint4(pb.x, pb.y, cull_zub(rw[0], rw[1], rw[2]), 0u); }
     uint4 *dst = reinterpret_cast<uint4 *>(g.recs + off);
     dst[0] = make_uint4((uint32_t)px[0], (uint32_t)py[0], (uint32_t)px[1], (uint32_t)py[1]);
     dst[1] = make_uint4((uint32_t)px[2], (uint32_t)py[2], f2u(sx[0]), f2u(sy[0]));
@@ -462,7 +462,7 @@ constexpr int BIN_COOP = 6;
 struct TileRange { int tx0, tx1, ty0, ty1; }; // inclusive-exclusive tile ranges (window-local)
 
 
-__device__ __forceinline__ TileRange tiles_of_pbox(const RasterArgs &a, const uint2 b)
+__device__ __forceinline__ TileRange tiles_of_pbox(const RasterArgs &a, const uint4 b)
 {
     const int mnx = (int)(short)(b.x & 0xFFFFu), mny = (int)(short)(b.x >> 16);
     const int mxx = (int)(short)(b.y & 0xFFFFu), mxy = (int)(short)(b.y >> 16);
@@ -484,29 +484,31 @@ __global__ __launch_bounds__(256) void k_bin(RasterArgs a)
     const uint32_t nwaves = gridDim.x * 4u;
     for (uint32_t base = wave * 64u; base < n; base += nwaves * 64u) {
         const uint32_t i = base + lane;
-        TileRange t = {0, 0, 0, 0};
-        if (i < n) t = tiles_of_pbox(a, a.pbox[i]);
+        const uint4 cu = i < n ? a.pbox[i] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
+        const TileRange t = tiles_of_pbox(a, cu);
         const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
         const int nt = ntx * nty;
-        auto visit = [&](uint32_t tri, int tx, int ty) {
+        auto visit = [&](const uint4 &ent, int tx, int ty) {
             if (ty % a.world != a.rank) return;
             const int tile = ty * a.tiles_x + tx;
             if constexpr (FILL) {
                 uint32_t pos = a.tile_offsets[tile] + atomicAdd(&a.tile_cursor[tile], 1u);
-                if (pos < a.bin_cap) a.bins[pos] = tri;
+                if (pos < a.bin_cap) a.bins[pos] = ent;
             } else {
                 atomicAdd(&a.tile_counts[tile], 1u);
             }
         };
+        const uint4 mine = make_uint4(i, cu.z, cu.x, cu.y);
         if (nt > 0 && nt <= BIN_COOP)
             for (int ty = t.ty0; ty < t.ty1; ++ty)
-                for (int tx = t.tx0; tx < t.tx1; ++tx) visit(i, tx, ty);
+                for (int tx = t.tx0; tx < t.tx1; ++tx) visit(mine, tx, ty);
         unsigned long long big = __ballot(nt > BIN_COOP);
         while (big) {
             const int src = __builtin_ctzll(big);
             big &= big - 1;
             const int bx0 = __shfl(t.tx0, src), by0 = __shfl(t.ty0, src), bnx = __shfl(ntx, src), bnt = __shfl(nt, src);
-            for (int k = lane; k < bnt; k += 64) visit(base + src, bx0 + k % bnx, by0 + k / bnx);
+            const uint4 ent = make_uint4(base + src, __shfl(cu.z, src), __shfl(cu.x, src), __shfl(cu.y, src));
+            for (int k = lane; k < bnt; k += 64) visit(ent, bx0 + k % bnx, by0 + k / bnx);
         }
     }
 }
@@ -576,11 +578,11 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_lds(RasterArgs a, uint32_t ntile
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int PF = 4; // bboxes of PF rounds are fetched up front: the loop is latency-bound otherwise
     for (uint32_t base0 = lo + wave * 64u; base0 < hi; base0 += PF * BIN_WG) {
-        uint2 pb[PF];
+        uint4 pb[PF];
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const uint32_t i = base0 + k * BIN_WG + lane;
-            pb[k] = i < hi ? a.pbox[i] : make_uint2(0u, 0u); // (0,0)-(0,0) is an empty box
+            pb[k] = i < hi ? a.pbox[i] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
         }
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
@@ -590,25 +592,27 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_lds(RasterArgs a, uint32_t ntile
             const TileRange t = tiles_of_pbox(a, pb[k]);
             const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
             const int nt = ntx * nty;
-            auto visit = [&](uint32_t tri, int tx, int ty) {
+            auto visit = [&](const uint4 &ent, int tx, int ty) {
                 if (ty % a.world != a.rank) return;
                 const int tile = ty * a.tiles_x + tx;
                 if constexpr (SCATTER) {
                     const uint32_t pos = atomicAdd(&s_hist[tile], 1u);
-                    if (pos < a.bin_cap) a.bins[pos] = tri;
+                    if (pos < a.bin_cap) a.bins[pos] = ent;
                 } else {
                     atomicAdd(&s_hist[tile], 1u);
                 }
             };
+            const uint4 mine = make_uint4(i, pb[k].z, pb[k].x, pb[k].y);
             if (nt > 0 && nt <= BIN_COOP)
                 for (int ty = t.ty0; ty < t.ty1; ++ty)
-                    for (int tx = t.tx0; tx < t.tx1; ++tx) visit(i, tx, ty);
+                    for (int tx = t.tx0; tx < t.tx1; ++tx) visit(mine, tx, ty);
             unsigned long long big = __ballot(nt > BIN_COOP);
             while (big) {
                 const int src = __builtin_ctzll(big);
                 big &= big - 1;
                 const int bx0 = __shfl(t.tx0, src), by0 = __shfl(t.ty0, src), bnx = __shfl(ntx, src), bnt = __shfl(nt, src);
-                for (int q = lane; q < bnt; q += 64) visit(base + src, bx0 + q % bnx, by0 + q / bnx);
+                const uint4 ent = make_uint4(base + src, __shfl(pb[k].z, src), __shfl(pb[k].x, src), __shfl(pb[k].y, src));
+                for (int q = lane; q < bnt; q += 64) visit(ent, bx0 + q % bnx, by0 + q / bnx);
             }
         }
     }

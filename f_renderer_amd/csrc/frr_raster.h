@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t n_cov = 0, n_nan = 0;
     for (uint32_t e = c.beg + wave; e < c.end; e += 4) {
-        const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e]);
+        const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e].x);
         sweep_triangle(a, c, t, lane, s_key, n_cov, n_nan);
     }
     if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
@@ -321,27 +321,18 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
     // z resolution is order independent); it only makes the hierarchical early-z below reject more.
     // Upper bound: rhw = (r0*a + r1*b) + r2*c with a+b+c = 1 up to a few roundings, so
     // |rhw| <= max|r_i| * (1 + 2^-18); NaN vertices disable it.
-    uint4 *__restrict__ ents = reinterpret_cast<uint4 *>(a.bins2);
+    uint4 *__restrict__ ents = a.bins2;
     {
         const bool sorted = !COUNT && c.end - c.beg > 2u * B;
-        auto make_ent = [&](uint32_t t) {
-            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + t);
-            const uint4 q0 = rp[0], q1 = rp[1], q3 = rp[3];
-            const float ar0 = fabsf(u2f(q3.x)), ar1 = fabsf(u2f(q3.y)), ar2 = fabsf(u2f(q3.z));
-            const float ub = fmaxf(fmaxf(ar0, ar1), ar2) * 1.000003814697265625f;
-            const uint32_t zub = (ar0 == ar0 && ar1 == ar1 && ar2 == ar2) ? zkey(ub) : 0xFFFFFFFFu;
-            const uint2 pb = pack_pbox((int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y);
-            return make_uint4(t, zub, pb.x, pb.y);
-        };
         auto bucket_of = [&](const uint4 &e) { return sorted ? 63u - ((e.y >> 21) & 63u) : 0u; };
         uint4 ce[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t e = c.beg + threadIdx.x + (uint32_t)(NW * 64) * k;
             ce[k] = make_uint4(0, 0, 0, 0);
-            if (e < c.end) { ce[k] = make_ent(a.bins[e]); atomicAdd(&s_bkt[bucket_of(ce[k])], 1u); }
+            if (e < c.end) { ce[k] = a.bins[e]; atomicAdd(&s_bkt[bucket_of(ce[k])], 1u); }
         }
-        for (uint32_t e = c.beg + threadIdx.x + 4u * NW * 64; e < c.end; e += NW * 64) atomicAdd(&s_bkt[bucket_of(make_ent(a.bins[e]))], 1u);
+        for (uint32_t e = c.beg + threadIdx.x + 4u * NW * 64; e < c.end; e += NW * 64) atomicAdd(&s_bkt[bucket_of(a.bins[e])], 1u);
         __syncthreads();
         if (w == 0) {
             const uint32_t x = s_bkt[lane];
@@ -355,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
             if (e < c.end) ents[atomicAdd(&s_bkt[bucket_of(ce[k])], 1u)] = ce[k];
         }
         for (uint32_t e = c.beg + threadIdx.x + 4u * NW * 64; e < c.end; e += NW * 64) {
-            const uint4 en = make_ent(a.bins[e]);
+            const uint4 en = a.bins[e];
             ents[atomicAdd(&s_bkt[bucket_of(en)], 1u)] = en;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
