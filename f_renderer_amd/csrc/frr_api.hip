@@ -15,10 +15,10 @@ using namespace frr;
 namespace {
 
 enum KernelId { KID_CLEAR, KID_GEOM_COUNT, KID_SCAN_BLOCKS, KID_GEOM_EMIT, KID_BIN_COUNT,
-                KID_TILE_SCAN, KID_BIN_FILL, KID_RASTER, KID_BIN_COLSCAN, KID_COUNT };
+                KID_TILE_SCAN, KID_BIN_FILL, KID_RASTER, KID_BIN_SEG, KID_COUNT };
 const char *const kKernelNames[KID_COUNT] = {"k_clear", "k_geom_count", "k_scan_blocks", "k_geom_emit",
                                              "k_bin_count", "k_tile_scan", "k_bin_fill",
-                                             "k_raster", "k_bin_colscan"};
+                                             "k_raster", "k_bin_seg"};
 
 struct Mesh {
     const float *dev = nullptr;
@@ -47,6 +47,8 @@ struct frr_ctx {
     uint32_t *block_sums = nullptr; size_t block_sums_cap = 0;
     unsigned long long *lb_status = nullptr; size_t lb_status_cap = 0;
     int bin_g = 0;             // FRR_BIN_G: override the number of binning chunks (dev)
+    uint32_t ent_slot_override = 0; // FRR_ENT_SLOT: per-tile slot of bins2 in records (tests of the overflow arena)
+    int bin_slot = 0;          // Counters::seg_total / ent_cursor slot of the latest draw (alternates)
     bool bin_atomics = false;  // FRR_BIN=atomics: force the global-atomic binning fallback (tests)
     size_t bin_cap_init = 0;   // FRR_BIN_CAP: initial bin capacity in entries (tests of the overflow path)
     bool geom_force_scan = false; // FRR_GEOM=scan: always launch k_scan_blocks (the path used beyond 8192 blocks)
@@ -174,7 +176,8 @@ int check_frame_counters(frr_ctx *c, Counters *host)
     if (h.overflow) {
         // grow what overflowed so that re-issuing the frame succeeds
         if (h.overflow & 2u) {
-            size_t need = (size_t)(h.bin_total + h.bin_total / 4 + 1024);
+            const uint64_t worst = std::max<uint64_t>(h.bin_total, std::max<uint64_t>(h.seg_total[0], h.seg_total[1]));
+            size_t need = (size_t)(worst + worst / 4 + 1024);
             if (ensure(c, c->bins, c->bin_cap, need) != FRR_OK) return FRR_ERR_NOMEM;
             if (ensure(c, c->bins2, c->bin2_cap, need) != FRR_OK) return FRR_ERR_NOMEM;
         }
@@ -274,6 +277,7 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     { const char *e = getenv("FRR_RASTER_NW"); const int v = e ? atoi(e) : 0; c->raster_nw = (v == 4 || v == 8 || v == 16) ? v : 0; }
     { const char *e = getenv("FRR_GEOM"); c->geom_twopass = !(e && strcmp(e, "lookback") == 0); c->geom_force_scan = e && strcmp(e, "scan") == 0; }
     { const char *e = getenv("FRR_BIN_G"); c->bin_g = e ? atoi(e) : 0; }
+    { const char *e = getenv("FRR_ENT_SLOT"); c->ent_slot_override = e ? (uint32_t)atoi(e) : 0u; }
     { const char *e = getenv("FRR_BIN"); c->bin_atomics = e && strcmp(e, "atomics") == 0; }
     { const char *e = getenv("FRR_BIN_CAP"); c->bin_cap_init = e ? (size_t)atoll(e) : 0; }
     if (stream) c->stream = (hipStream_t)stream;
@@ -518,21 +522,28 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     a.bins2 = c->bins2;
     a.bins = c->bins; a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xFFFFFFFFu);
     a.color = c->color; a.depth = c->depth; a.tri_id = c->tri_id; a.cnt = c->cnt;
-    if (ntiles <= BIN_LDS_MAX_TILES && !c->bin_atomics) {
-        // LDS multi-split (no global atomics): G chunk workgroups, ~3K triangles each
+    a.seg = nullptr; a.nseg = 0; a.slot = 0;
+    if (ntiles <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep) {
+        // segmented LDS multi-split (one launch, no per-entry global atomics): G chunk workgroups, ~3K triangles each
         uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + 3071) / 3072, 1), BIN_MAX_G);
         if (c->bin_g > 0) G = (uint32_t)std::min(c->bin_g, BIN_MAX_G);
-        if ((rc = ensure(c, c->bin_matrix, c->bin_matrix_cap, (size_t)BIN_MAX_G * c->max_tiles)) != FRR_OK) return rc;
+        if ((rc = ensure(c, c->bin_matrix, c->bin_matrix_cap, (size_t)BIN_MAX_G * ((size_t)c->max_tiles + 1))) != FRR_OK) return rc;
         const size_t lds = (size_t)ntiles * sizeof(uint32_t);
         if (!c->lds_attr_set) {
-            HIP_TRY(c, hipFuncSetAttribute((const void *)k_bin_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_LDS_MAX_TILES * 4));
-            HIP_TRY(c, hipFuncSetAttribute((const void *)k_bin_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_LDS_MAX_TILES * 4));
+            HIP_TRY(c, hipFuncSetAttribute((const void *)k_bin_seg, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_LDS_MAX_TILES * 4));
             c->lds_attr_set = true;
         }
-        { ProfScope p(c, KID_BIN_COUNT); hipLaunchKernelGGL(k_bin_lds<false>, dim3(G), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix); }
-        { ProfScope p(c, KID_BIN_COLSCAN); hipLaunchKernelGGL(k_bin_colscan, dim3((ntiles + 31) / 32), dim3(256), 0, c->stream, c->bin_matrix, G, ntiles, c->tile_counts); }
-        { ProfScope p(c, KID_TILE_SCAN); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, a, ntiles); }
-        { ProfScope p(c, KID_BIN_FILL); hipLaunchKernelGGL(k_bin_lds<true>, dim3(G), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix); }
+        c->bin_slot ^= 1;
+        a.seg = c->bin_matrix; a.nseg = G; a.slot = c->bin_slot;
+        // near-first copies (bins2): a fixed slot per tile, 8x the mean tile load, + an overflow arena of bin_cap records
+        uint64_t S = std::max<uint64_t>(256, (c->geom_ntris * 16 + ntiles - 1) / ntiles);
+        S = std::min<uint64_t>(S, ((uint64_t)1 << 30) / ntiles);
+        if (c->ent_slot_override) S = c->ent_slot_override;
+        a.ent_slot = (uint32_t)S;
+        a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xBFFFFFFFu);
+        if ((rc = ensure(c, c->bins2, c->bin2_cap, (size_t)ntiles * S + a.bin_cap)) != FRR_OK) return rc;
+        a.bins2 = c->bins2;
+        { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix, a.slot); }
     } else {
         // fallback for frames with more tiles than fit LDS counters: global atomics
         const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(c->geom_ntris * FRR_MAX_OUT_TRIS, c->setup_cap) + 255) / 256, 2048);
@@ -620,7 +631,7 @@ int frr_get_stats(frr_ctx *c, frr_stats *out)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     out->tris_in = h.tris_in;
     out->tris_setup = (uint64_t)h.tri_base + h.n_setup;
-    out->bin_entries = h.bin_entries_frame;
+    out->bin_entries = h.bin_entries_frame + h.seg_total[0] + h.seg_total[1];
     out->frag_covered = h.frag_covered;
     out->frag_nan = h.frag_nan;
     out->draws = h.draws;

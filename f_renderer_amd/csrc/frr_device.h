@@ -38,6 +38,8 @@ struct Counters {
     uint32_t need_setup;    // setup triangles the current draw needs (valid even on overflow)
     uint32_t ticket;        // dynamic block ids of the single-pass geometry kernel
     uint32_t pad0;
+    unsigned long long seg_total[2]; // segmented binning: entries reserved by the current / previous draw (slots alternate per draw)
+    uint32_t ent_cursor[2];          // tile kernel: space handed out in the overflow arena of bins2 (same slots)
     unsigned long long dbg[8]; // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py)
 };
 
@@ -81,6 +83,10 @@ struct RasterArgs {
     uint32_t *tile_counts;            // [ntiles]
     uint32_t *tile_offsets;           // [ntiles+1]
     uint32_t *tile_cursor;            // [ntiles]
+    const uint32_t *seg;              // segmented binning: [nseg][ntiles+1] segment starts (+ end sentinel) into bins; nseg == 0: CSR (tile_offsets)
+    uint32_t nseg;
+    int32_t slot;                     // which Counters::seg_total / ent_cursor slot this draw uses
+    uint32_t ent_slot;                // segmented binning: bins2 = [ntiles][ent_slot] fixed slots + an overflow arena of bin_cap records
     uint4 *bins;                      // one 16-byte cull record {tri, zub, bbox.x, bbox.y} per (triangle, tile) pair, CSR by tile
     uint4 *bins2;                     // the same records in near-first order per tile (written by the tile kernel's pre-pass)
     uint32_t bin_cap;

@@ -1,7 +1,7 @@
 // frr_kernels.h -- the gfx950 kernels of the rasterization path (wave64, LDS-tiled).
 //
-// Frame = clear -> per draw { geometry: count, scan, emit (clipping inside, wave-cooperative) ;
-// binning: LDS multi-split count, column scan, CSR scan, scatter ; raster+resolve per 32x32 tile }.  See DESIGN.md for the roofline of each kernel.
+// Frame = clear -> per draw { geometry: count, emit (clipping inside, wave-cooperative) ;
+// binning: one segmented LDS multi-split launch ; raster+resolve per 32x32 tile }.  See DESIGN.md for the roofline of each kernel.
 #pragma once
 #include "frr_device.h"
 #include <type_traits>
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void k_clear(uint4 *__restrict__ color, uint4 
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cnt->n_setup = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
+        cnt->seg_total[0] = cnt->seg_total[1] = 0ull; cnt->ent_cursor[0] = cnt->ent_cursor[1] = 0u;
         cnt->frag_covered = 0; cnt->frag_nan = 0; cnt->tris_in = 0; cnt->bin_entries_frame = 0; cnt->draws = 0;
         for (int k = 0; k < 8; ++k) cnt->dbg[k] = 0;
     }
@@ -547,28 +548,34 @@ __global__ __launch_bounds__(1024) void k_tile_scan(RasterArgs a, uint32_t ntile
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2' binning without global atomics (default path): an LDS multi-split.
-//   k_bin_lds<false>: workgroup g of G histograms its contiguous chunk of setup triangles over
-//                     the tiles in LDS (ds_add) and stores the row M[g][*] (coalesced);
-//   k_bin_colscan   : per tile, exclusive prefix over g of M[*][tile] (in LDS, 32 tiles per
-//                     workgroup) and the tile total -> tile_counts;
-//   k_tile_scan     : exclusive scan of the totals -> tile_offsets (CSR);
-//   k_bin_lds<true> : workgroup g loads cursor[tile] = tile_offsets[tile] + M[g][tile] into LDS and
-//                     scatters its triangles' indices with returning LDS atomics + plain stores.
-// Scattered memory-side atomics (k_bin above: ~7 G/s on MI355X) are avoided entirely; the old path
-// remains as the fallback when the tile count does not fit LDS.
+// K2' binning in ONE launch, without per-entry global atomics (default path): a segmented LDS
+// multi-split.  Workgroup g of G owns a contiguous chunk of the setup triangles and
+//   1. histograms the chunk over the tiles in LDS (ds_add);
+//   2. scans the histogram (exclusive, over tiles) and reserves its T_g entries of `bins` with ONE
+//      global atomic (base_g): its records for tile t then live at base_g + prefix_g[t] .. -- a
+//      private, contiguous, tile-sorted region;
+//   3. publishes the row seg[g][0..ntiles] = those starts (+ the end sentinel);
+//   4. walks the chunk again (L2-hot) and scatters the 16-byte cull records with returning LDS atomics.
+// The tile kernel reads column t of `seg` (G (start,end) pairs) and walks the segments; no column
+// scan, no CSR scan and no second launch are needed.  The global-atomic CSR path (k_bin above) remains
+// as the fallback when the tile count does not fit LDS.
 // ---------------------------------------------------------------------------------------------
 constexpr int BIN_WG = 512;
 constexpr int BIN_MAX_G = 256;
 constexpr uint32_t BIN_LDS_MAX_TILES = 36864; // 144 KiB of u32 counters
 
-template <bool SCATTER>
-__global__ __launch_bounds__(BIN_WG) void k_bin_lds(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ M)
+__global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg, int slot)
 {
     extern __shared__ uint32_t s_hist[]; // [ntiles]
+    __shared__ uint32_t s_w[BIN_WG / 64];
+    __shared__ uint32_t s_base;
     const uint32_t g = blockIdx.x, G = gridDim.x;
-    uint32_t *__restrict__ row = M + (size_t)g * ntiles;
-    for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) s_hist[t] = SCATTER ? a.tile_offsets[t] + row[t] : 0u;
+    for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) s_hist[t] = 0u;
+    if (g == 0 && threadIdx.x == 0) { // the other slot belongs to the previous draw, which has drained
+        a.cnt->bin_entries_frame += a.cnt->seg_total[slot ^ 1];
+        a.cnt->seg_total[slot ^ 1] = 0ull;
+        a.cnt->ent_cursor[slot ^ 1] = 0u;
+    }
     __syncthreads();
     const uint32_t n = a.cnt->n_setup;
     uint32_t chunk = (n + G - 1) / G;
@@ -577,81 +584,79 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_lds(RasterArgs a, uint32_t ntile
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int PF = 4; // bboxes of PF rounds are fetched up front: the loop is latency-bound otherwise
-    for (uint32_t base0 = lo + wave * 64u; base0 < hi; base0 += PF * BIN_WG) {
-        uint4 pb[PF];
+    auto walk = [&](auto scatter_tag) {
+        constexpr bool SCATTER = decltype(scatter_tag)::value;
+        for (uint32_t base0 = lo + wave * 64u; base0 < hi; base0 += PF * BIN_WG) {
+            uint4 pb[PF];
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const uint32_t i = base0 + k * BIN_WG + lane;
-            pb[k] = i < hi ? a.pbox[i] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
-        }
+            for (int k = 0; k < PF; ++k) {
+                const uint32_t i = base0 + k * BIN_WG + lane;
+                pb[k] = i < hi ? a.pbox[i] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
+            }
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const uint32_t base = base0 + k * BIN_WG;
-            if (base >= hi) break;
-            const uint32_t i = base + lane;
-            const TileRange t = tiles_of_pbox(a, pb[k]);
-            const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
-            const int nt = ntx * nty;
-            auto visit = [&](const uint4 &ent, int tx, int ty) {
-                if (ty % a.world != a.rank) return;
-                const int tile = ty * a.tiles_x + tx;
-                if constexpr (SCATTER) {
-                    const uint32_t pos = atomicAdd(&s_hist[tile], 1u);
-                    if (pos < a.bin_cap) a.bins[pos] = ent;
-                } else {
-                    atomicAdd(&s_hist[tile], 1u);
+            for (int k = 0; k < PF; ++k) {
+                const uint32_t base = base0 + k * BIN_WG;
+                if (base >= hi) break;
+                const uint32_t i = base + lane;
+                const TileRange t = tiles_of_pbox(a, pb[k]);
+                const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
+                const int nt = ntx * nty;
+                auto visit = [&](const uint4 &ent, int tx, int ty) {
+                    if (ty % a.world != a.rank) return;
+                    const int tile = ty * a.tiles_x + tx;
+                    if constexpr (SCATTER) {
+                        const uint32_t pos = atomicAdd(&s_hist[tile], 1u);
+                        if (pos < a.bin_cap) a.bins[pos] = ent;
+                    } else {
+                        atomicAdd(&s_hist[tile], 1u);
+                    }
+                };
+                const uint4 mine = make_uint4(i, pb[k].z, pb[k].x, pb[k].y);
+                if (nt > 0 && nt <= BIN_COOP)
+                    for (int ty = t.ty0; ty < t.ty1; ++ty)
+                        for (int tx = t.tx0; tx < t.tx1; ++tx) visit(mine, tx, ty);
+                unsigned long long big = __ballot(nt > BIN_COOP);
+                while (big) {
+                    const int src = __builtin_ctzll(big);
+                    big &= big - 1;
+                    const int bx0 = __shfl(t.tx0, src), by0 = __shfl(t.ty0, src), bnx = __shfl(ntx, src), bnt = __shfl(nt, src);
+                    const uint4 ent = make_uint4(base + src, __shfl(pb[k].z, src), __shfl(pb[k].x, src), __shfl(pb[k].y, src));
+                    for (int q = lane; q < bnt; q += 64) visit(ent, bx0 + q % bnx, by0 + q / bnx);
                 }
-            };
-            const uint4 mine = make_uint4(i, pb[k].z, pb[k].x, pb[k].y);
-            if (nt > 0 && nt <= BIN_COOP)
-                for (int ty = t.ty0; ty < t.ty1; ++ty)
-                    for (int tx = t.tx0; tx < t.tx1; ++tx) visit(mine, tx, ty);
-            unsigned long long big = __ballot(nt > BIN_COOP);
-            while (big) {
-                const int src = __builtin_ctzll(big);
-                big &= big - 1;
-                const int bx0 = __shfl(t.tx0, src), by0 = __shfl(t.ty0, src), bnx = __shfl(ntx, src), bnt = __shfl(nt, src);
-                const uint4 ent = make_uint4(base + src, __shfl(pb[k].z, src), __shfl(pb[k].x, src), __shfl(pb[k].y, src));
-                for (int q = lane; q < bnt; q += 64) visit(ent, bx0 + q % bnx, by0 + q / bnx);
             }
         }
-    }
-    if constexpr (!SCATTER) {
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) row[t] = s_hist[t];
-    }
-}
-
-// M[g][tile] -> exclusive prefix over g (in place); tile_counts[tile] = column total.
-// One workgroup per 32 tiles: 256 threads = 32 tile columns x 8 segments of g.
-__global__ __launch_bounds__(256) void k_bin_colscan(uint32_t *__restrict__ M, uint32_t G, uint32_t ntiles,
-                                                     uint32_t *__restrict__ tile_counts)
-{
-    __shared__ uint32_t s[BIN_MAX_G][32];
-    __shared__ uint32_t s_part[8][32];
-    const uint32_t tl = threadIdx.x & 31, gs = threadIdx.x >> 5;
-    const uint32_t t = blockIdx.x * 32 + tl;
-    const bool ok = t < ntiles;
-    {
-        uint32_t v[BIN_MAX_G / 8];
-#pragma unroll
-        for (int k = 0; k < BIN_MAX_G / 8; ++k) { const uint32_t g = gs + 8u * k; v[k] = (ok && g < G) ? M[(size_t)g * ntiles + t] : 0u; }
-#pragma unroll
-        for (int k = 0; k < BIN_MAX_G / 8; ++k) { const uint32_t g = gs + 8u * k; if (g < G) s[g][tl] = v[k]; }
-    }
+    };
+    walk(std::false_type{});
     __syncthreads();
-    const uint32_t seg = (G + 7) / 8, g0 = min(G, gs * seg), g1 = min(G, g0 + seg);
+    // exclusive scan over tiles, in place: thread i owns the slice [i*per, (i+1)*per)
+    const uint32_t per = (ntiles + BIN_WG - 1) / BIN_WG;
+    const uint32_t t0 = min(ntiles, threadIdx.x * per), t1 = min(ntiles, t0 + per);
     uint32_t sum = 0;
-    for (uint32_t g = g0; g < g1; ++g) sum += s[g][tl];
-    s_part[gs][tl] = sum;
+    for (uint32_t t = t0; t < t1; ++t) sum += s_hist[t];
+    const uint32_t inc = wave_incl_scan(sum);
+    if (lane == 63) s_w[wave] = inc;
     __syncthreads();
-    uint32_t run = 0, total = 0;
+    uint32_t wbase = 0, total = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) { const uint32_t x = s_part[k][tl]; if (k < gs) run += x; total += x; }
-    for (uint32_t g = g0; g < g1; ++g) { const uint32_t x = s[g][tl]; s[g][tl] = run; run += x; }
-    if (gs == 0 && ok) tile_counts[t] = total;
+    for (int k = 0; k < BIN_WG / 64; ++k) { const uint32_t x = s_w[k]; if (k < (int)wave) wbase += x; total += x; }
+    if (threadIdx.x == 0) {
+        const unsigned long long b64 = atomicAdd(&a.cnt->seg_total[slot], (unsigned long long)total);
+        uint32_t base = (uint32_t)b64;
+        if (b64 + total > (unsigned long long)a.bin_cap) { atomicOr(&a.cnt->overflow, 2u); base = a.bin_cap; } // frame flagged invalid; nothing of this chunk is stored
+        s_base = base;
+    }
     __syncthreads();
-    for (uint32_t g = gs; g < G; g += 8) if (ok) M[(size_t)g * ntiles + t] = s[g][tl];
+    const uint32_t base = s_base;
+    uint32_t *__restrict__ row = seg + (size_t)g * (ntiles + 1);
+    {
+        uint32_t run = base + (wbase + inc - sum);
+        for (uint32_t t = t0; t < t1; ++t) { const uint32_t x = s_hist[t]; s_hist[t] = min(run, a.bin_cap); run += x; }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) row[t] = s_hist[t];
+    if (threadIdx.x == 0) row[ntiles] = (uint32_t)min((unsigned long long)base + total, (unsigned long long)a.bin_cap);
+    __syncthreads(); // rows are read from LDS above before the cursors start moving
+    walk(std::true_type{});
 }
 
 } // namespace frr

@@ -44,8 +44,11 @@ __device__ __forceinline__ TileCtx tile_ctx(const RasterArgs &a)
     c.lx0 = tx * TILE; c.ly0 = ty * TILE;
     c.tw = min(TILE, a.win_w - c.lx0); c.th = min(TILE, a.win_h - c.ly0);
     c.ax0 = a.x0 + c.lx0; c.ay0 = a.y0 + c.ly0;
-    c.beg = a.tile_offsets[c.tile];
-    c.end = min(a.tile_offsets[c.tile + 1], a.bin_cap);
+    c.beg = c.end = 0;
+    if (a.nseg == 0) { // CSR binning; with segmented binning the tile kernel derives its range itself
+        c.beg = a.tile_offsets[c.tile];
+        c.end = min(a.tile_offsets[c.tile + 1], a.bin_cap);
+    }
     return c;
 }
 
@@ -305,34 +308,78 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
     __shared__ __attribute__((aligned(16))) uint32_t s_hz[HZ_SIZE]; // hierarchical z (see hiz_rebuild)
     __shared__ uint32_t s_next;
     __shared__ uint32_t s_bkt[64];
-    const TileCtx c = tile_ctx(a);
-    if (c.beg >= c.end) return;
+    __shared__ uint32_t s_segpre[BIN_MAX_G + 1];      // segmented binning: entries of this tile before segment g
+    __shared__ uint32_t s_segsrc[BIN_MAX_G];          //                     where segment g starts in a.bins
+    __shared__ uint32_t s_w4[4];
+    __shared__ uint32_t s_ebase;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TileCtx c = tile_ctx(a);
+    const bool segmented = a.nseg != 0;
+    if (segmented) {
+        // column c.tile of the segment table: (start, end) of this tile's records in each chunk's region
+        uint32_t s0 = 0, cn = 0;
+        if (threadIdx.x < a.nseg) {
+            const uint32_t *r = a.seg + (size_t)threadIdx.x * ((size_t)a.tiles_x * a.tiles_y + 1) + c.tile;
+            s0 = r[0];
+            cn = r[1] - s0;
+        }
+        const uint32_t inc = wave_incl_scan_dpp(cn);
+        if (lane == 63 && w < 4) s_w4[w] = inc;
+        __syncthreads();
+        const uint32_t w0 = s_w4[0], w1 = s_w4[1], w2 = s_w4[2], w3 = s_w4[3];
+        const uint32_t total = __builtin_amdgcn_readfirstlane((w0 + w1) + (w2 + w3)); // wave-uniform, and the compiler should know
+        if (total == 0u) return;
+        if (threadIdx.x < BIN_MAX_G) {
+            s_segpre[threadIdx.x] = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u) + inc - cn;
+            s_segsrc[threadIdx.x] = s0;
+        }
+        if (threadIdx.x == 0) {
+            s_segpre[BIN_MAX_G] = total;
+            // where this tile's near-first copy goes: its own fixed slot of bins2, or -- a tile hotter than
+            // the slot -- space from the shared overflow arena behind the slots.  (One atomic per tile on a
+            // single address costs ~17 ns each, serialised across the whole launch; hence the slots.)
+            const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
+            s_ebase = total <= a.ent_slot ? (uint32_t)c.tile * a.ent_slot
+                                          : ntiles * a.ent_slot + atomicAdd(&a.cnt->ent_cursor[a.slot], total);
+        }
+        __syncthreads();
+        c.beg = __builtin_amdgcn_readfirstlane(s_ebase); // this tile's range of the near-first copy (bins2)
+        c.end = c.beg + total;
+    } else if (c.beg >= c.end) {
+        return;
+    }
+    // k-th record of this tile, k in [0, c.end - c.beg)
+    auto source = [&](uint32_t k) -> uint4 {
+        if (!segmented) return a.bins[c.beg + k];
+        uint32_t g = 0;
+#pragma unroll
+        for (int st = BIN_MAX_G / 2; st >= 1; st >>= 1) if (s_segpre[g + st] <= k) g += st;
+        return a.bins[s_segsrc[g] + (k - s_segpre[g])];
+    };
     tile_load_keys(a, c, s_key, ~0ull);
     if (threadIdx.x == 0) s_next = 0;
     if (threadIdx.x < 64) s_bkt[threadIdx.x] = 0;
     __syncthreads();
 
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    // ---- pre-pass: every bin entry becomes a 16-byte cull record {triangle, zkey of an upper bound of
-    // its rhw, pixel bbox}, written in NEAR-FIRST order (a 64-bucket sort on 4 exponent + 2 mantissa
-    // bits of the bound) into this tile's own range of `ents`.  The order cannot change any output (the
-    // z resolution is order independent); it only makes the hierarchical early-z below reject more.
-    // Upper bound: rhw = (r0*a + r1*b) + r2*c with a+b+c = 1 up to a few roundings, so
-    // |rhw| <= max|r_i| * (1 + 2^-18); NaN vertices disable it.
+    // ---- pre-pass: this tile's 16-byte cull records {triangle, zkey of an upper bound of its rhw
+    // (cull_zub), pixel bbox} are copied in NEAR-FIRST order (a 64-bucket sort on 4 exponent + 2
+    // mantissa bits of the bound) into the tile's own range of `ents`.  The order cannot change any
+    // output (the z resolution is order independent); it only makes the hierarchical early-z below
+    // reject more.
     uint4 *__restrict__ ents = a.bins2;
     {
-        const bool sorted = !COUNT && c.end - c.beg > 2u * B;
+        const uint32_t nent = c.end - c.beg;
+        const bool sorted = !COUNT && nent > 2u * B;
         auto bucket_of = [&](const uint4 &e) { return sorted ? 63u - ((e.y >> 21) & 63u) : 0u; };
         uint4 ce[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t e = c.beg + threadIdx.x + (uint32_t)(NW * 64) * k;
+            const uint32_t e = threadIdx.x + (uint32_t)(NW * 64) * k;
             ce[k] = make_uint4(0, 0, 0, 0);
-            if (e < c.end) { ce[k] = a.bins[e]; atomicAdd(&s_bkt[bucket_of(ce[k])], 1u); }
+            if (e < nent) { ce[k] = source(e); atomicAdd(&s_bkt[bucket_of(ce[k])], 1u); }
         }
-        for (uint32_t e = c.beg + threadIdx.x + 4u * NW * 64; e < c.end; e += NW * 64) atomicAdd(&s_bkt[bucket_of(a.bins[e])], 1u);
+        for (uint32_t e = threadIdx.x + 4u * NW * 64; e < nent; e += NW * 64) atomicAdd(&s_bkt[bucket_of(source(e))], 1u);
         __syncthreads();
         if (w == 0) {
             const uint32_t x = s_bkt[lane];
@@ -342,11 +389,11 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t e = c.beg + threadIdx.x + (uint32_t)(NW * 64) * k;
-            if (e < c.end) ents[atomicAdd(&s_bkt[bucket_of(ce[k])], 1u)] = ce[k];
+            const uint32_t e = threadIdx.x + (uint32_t)(NW * 64) * k;
+            if (e < nent) ents[atomicAdd(&s_bkt[bucket_of(ce[k])], 1u)] = ce[k];
         }
-        for (uint32_t e = c.beg + threadIdx.x + 4u * NW * 64; e < c.end; e += NW * 64) {
-            const uint4 en = a.bins[e];
+        for (uint32_t e = threadIdx.x + 4u * NW * 64; e < nent; e += NW * 64) {
+            const uint4 en = source(e);
             ents[atomicAdd(&s_bkt[bucket_of(en)], 1u)] = en;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

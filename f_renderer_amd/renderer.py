@@ -271,7 +271,7 @@ class Renderer:
         return float(ms.value)
 
     KERNELS = ("k_clear", "k_geom_count", "k_scan_blocks", "k_geom_emit", "k_bin_count",
-               "k_tile_scan", "k_bin_fill", "k_raster", "k_bin_colscan")
+               "k_tile_scan", "k_bin_fill", "k_raster", "k_bin_seg")
 
     def profile_enable(self, on=True, kernels=None):
         """Bracket launches with HIP events: all kernels (on=True), none (False) or the named ones."""

@@ -164,7 +164,7 @@ int frr_event_elapsed_ms(frr_ctx *ctx, int a, int b, float *ms);
 /* per-kernel accumulated device time (ms) and launch count since frr_profile_reset.  `mask`:
  * 0 = off, -1 = every kernel, else OR of (1 << index) with index in the order k_clear,
  * k_geom_count, k_scan_blocks, k_geom_emit, k_bin_count, k_tile_scan, k_bin_fill, k_raster,
- * k_bin_colscan.  A profiled launch is bracketed by two HIP events on the ctx stream. */
+ * k_bin_seg.  A profiled launch is bracketed by two HIP events on the ctx stream. */
 int frr_profile_enable(frr_ctx *ctx, int mask);
 int frr_profile_reset(frr_ctx *ctx);
 int frr_profile_get(frr_ctx *ctx, const char *kernel, float *total_ms, uint32_t *launches);

@@ -216,3 +216,25 @@ def test_vertex_sort_near_ties_and_axes(oracle):
         _, d, t = r.readback()
         np.testing.assert_array_equal(t, f.tri_id)
         np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+
+
+@pytest.mark.parametrize("slot", [1, 16])
+def test_hot_tiles_use_the_overflow_arena(oracle, monkeypatch, slot):
+    """Segmented binning gives every tile a fixed slot for its near-first record copy; tiles with more
+    records than the slot allocate from the shared overflow arena.  Force that with a tiny slot."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    monkeypatch.setenv("FRR_ENT_SLOT", str(slot))
+    W, H = 320, 200
+    tris = scenes.random_clip_triangles(6000, W, H, seed=9, spread=1.1)
+    f = _oracle_depth(oracle, tris, W, H)
+    r = fr.Renderer(W, H)
+    m = r.upload_mesh(tris, fr.VS_CLIP)
+    for _ in range(3):                                     # consecutive draws alternate the counter slots
+        r.clear()
+        r.draw(m, fr.PS_DEPTH)
+        _, d, t = r.readback()
+        np.testing.assert_array_equal(t, f.tri_id)
+        np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+        assert r.stats()["frag_covered"] == f.counters.frag_covered
+        assert r.stats()["bin_entries"] > 0
