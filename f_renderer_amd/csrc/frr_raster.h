@@ -307,6 +307,7 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
     __shared__ uint32_t s_aq[NW][64];               // per wave: triangles that survived phase 1a
     __shared__ __attribute__((aligned(16))) uint32_t s_hz[HZ_SIZE]; // hierarchical z (see hiz_rebuild)
     __shared__ uint32_t s_next;
+    __shared__ uint32_t s_dirty;                    // keys changed since the hierarchical z was last rebuilt
     __shared__ uint32_t s_bkt[64];
     __shared__ uint32_t s_segpre[BIN_MAX_G + 1];      // segmented binning: entries of this tile before segment g
     __shared__ uint32_t s_segsrc[BIN_MAX_G];          //                     where segment g starts in a.bins
@@ -358,8 +359,9 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
         return a.bins[s_segsrc[g] + (k - s_segpre[g])];
     };
     tile_load_keys(a, c, s_key, ~0ull);
-    if (threadIdx.x == 0) s_next = 0;
+    if (threadIdx.x == 0) { s_next = 0; s_dirty = 1u; }
     if (threadIdx.x < 64) s_bkt[threadIdx.x] = 0;
+    if (threadIdx.x < HZ_SIZE) s_hz[threadIdx.x] = 0u; // "nothing can be culled" until the first rebuild lands
     __syncthreads();
 
     // ---- pre-pass: this tile's 16-byte cull records {triangle, zkey of an upper bound of its rhw
@@ -422,7 +424,12 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
                 input_done = true;
             } else {
                 const int nb64 = (int)min((uint32_t)SPAN_CULL, c.end - e0);
-                hiz_rebuild(s_key, s_hz, lane);
+                // the minima are rebuilt only if some wave has resolved fragments since the last rebuild
+                // (a stale minimum is a lower one: still conservative)
+                if (__builtin_amdgcn_readfirstlane(s_dirty) != 0u) {
+                    if (lane == 0) s_dirty = 0u;
+                    hiz_rebuild(s_key, s_hz, lane);
+                }
                 wave_lds_fence();
                 const bool valid = lane < nb64;
                 const uint4 en = valid ? ents[e0 + lane] : make_uint4(0, 0, 0, 0);
@@ -604,6 +611,7 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
                 }
                 seg_advance(g_lo, g_hi, qbase, qcarry);
             }
+            if (lane == 0) s_dirty = 1u;
             wave_lds_fence(); // s_q / s_hfrag are rewritten by the next row window
         }
 
