@@ -638,7 +638,7 @@ int frr_get_stats(frr_ctx *c, frr_stats *out)
     out->overflow = h.overflow;
     if (getenv("FRR_DEBUG_PRINT")) {
         fprintf(stderr, "frr dbg:");
-        for (int k = 0; k < 8; ++k) fprintf(stderr, " %llu", h.dbg[k]);
+        for (int k = 0; k < 12; ++k) fprintf(stderr, " %llu", h.dbg[k]);
         fprintf(stderr, "\n");
     }
     return FRR_OK;

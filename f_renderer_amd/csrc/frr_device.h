@@ -40,7 +40,7 @@ struct Counters {
     uint32_t pad0;
     unsigned long long seg_total[2]; // segmented binning: entries reserved by the current / previous draw (slots alternate per draw)
     uint32_t ent_cursor[2];          // tile kernel: space handed out in the overflow arena of bins2 (same slots)
-    unsigned long long dbg[8]; // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py)
+    unsigned long long dbg[12]; // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py)
 };
 
 struct DevUniforms {

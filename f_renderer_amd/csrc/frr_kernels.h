@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_clear(uint4 *__restrict__ color, uint4 
         cnt->n_setup = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
         cnt->seg_total[0] = cnt->seg_total[1] = 0ull; cnt->ent_cursor[0] = cnt->ent_cursor[1] = 0u;
         cnt->frag_covered = 0; cnt->frag_nan = 0; cnt->tris_in = 0; cnt->bin_entries_frame = 0; cnt->draws = 0;
-        for (int k = 0; k < 8; ++k) cnt->dbg[k] = 0;
+        for (int k = 0; k < 12; ++k) cnt->dbg[k] = 0;
     }
 }
 // tail elements when W*H is not a multiple of 4

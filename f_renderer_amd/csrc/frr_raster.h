@@ -256,8 +256,8 @@ __device__ __forceinline__ void edge_bound(int Er, int A, int thr, int &lo, int 
 // current keys, s_hiz8[by*4 + seg] = min over the 8x8 block.  Depth keys only grow, so a value read
 // late, or written by another wave a moment ago, is still a valid lower bound: no synchronisation.
 // Layout of the array hz[HZ_SIZE]: [HZ_SEG + row*4 + seg] 8-pixel row segments, [HZ_BLK + by*4 + bx]
-// 8x8 blocks, [HZ_QUAD + qy*2 + qx] 16x16 quads, [HZ_ROW + row] whole tile rows.
-constexpr int HZ_SEG = 0, HZ_BLK = 128, HZ_QUAD = 144, HZ_ROW = 148, HZ_SIZE = 180;
+// 8x8 blocks, [HZ_QUAD + qy*2 + qx] 16x16 quads, [HZ_C4 + row*8 + cell] 4-pixel cells of a row.
+constexpr int HZ_SEG = 0, HZ_BLK = 128, HZ_QUAD = 144, HZ_C4 = 148, HZ_SIZE = 404;
 __device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uint32_t *hz, int lane)
 {
     // consecutive lanes read consecutive 16-byte chunks (2 keys): conflict-free; 4 lanes = one segment
@@ -267,6 +267,7 @@ __device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uin
         const uint4 v = p[64 * k + lane];
         uint32_t m = min(v.y, v.w);
         m = min(m, (uint32_t)__shfl_xor((int)m, 1));
+        if ((lane & 1) == 0) hz[HZ_C4 + 32 * k + (lane >> 1)] = m;
         m = min(m, (uint32_t)__shfl_xor((int)m, 2));
         if ((lane & 3) == 0) hz[HZ_SEG + 16 * k + (lane >> 2)] = m;
     }
@@ -277,10 +278,6 @@ __device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uin
 #pragma unroll
         for (int r = 0; r < 8; ++r) m = min(m, hz[HZ_SEG + (by * 8 + r) * 4 + bx]);
         hz[HZ_BLK + lane] = m;
-    } else if (lane < 48) {                // whole rows: 4 segments
-        const int row = lane - 16;
-        const uint4 v = *reinterpret_cast<const uint4 *>(&hz[HZ_SEG + row * 4]);
-        hz[HZ_ROW + row] = min(min(v.x, v.y), min(v.z, v.w));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane < 4) {                        // 16x16 quads: 2x2 blocks
@@ -361,7 +358,7 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
     tile_load_keys(a, c, s_key, ~0ull);
     if (threadIdx.x == 0) { s_next = 0; s_dirty = 1u; }
     if (threadIdx.x < 64) s_bkt[threadIdx.x] = 0;
-    if (threadIdx.x < HZ_SIZE) s_hz[threadIdx.x] = 0u; // "nothing can be culled" until the first rebuild lands
+    for (int i = threadIdx.x; i < HZ_SIZE; i += NW * 64) s_hz[i] = 0u; // "nothing can be culled" until the first rebuild lands
     __syncthreads();
 
     // ---- pre-pass: this tile's 16-byte cull records {triangle, zkey of an upper bound of its rhw
@@ -408,6 +405,7 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
     uint32_t n_cov = 0, n_nan = 0;
 #ifdef FRR_DEBUG_COUNTERS
     uint32_t d_tri = 0, d_alive = 0, d_rows = 0, d_spans = 0, d_spans_live = 0, d_frags = 0, d_fwin = 0, d_rwin = 0;
+    uint32_t d_pre = 0, d_win = 0, d_rebuild = 0; // fragments a per-pixel zub test would skip; fragments that took the pixel; hi-z rebuilds
 #endif
 
     int aq_n = 0;            // survivors waiting in this wave's queue (wave-uniform)
@@ -429,6 +427,9 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
                 if (__builtin_amdgcn_readfirstlane(s_dirty) != 0u) {
                     if (lane == 0) s_dirty = 0u;
                     hiz_rebuild(s_key, s_hz, lane);
+#ifdef FRR_DEBUG_COUNTERS
+                    ++d_rebuild;
+#endif
                 }
                 wave_lds_fence();
                 const bool valid = lane < nb64;
@@ -563,11 +564,24 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
 #endif
             seg_advance(h_lo, h_hi, jbase, jcarry);
             if (COUNT) n_cov += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp((uint32_t)len), 63);
-            // span-level early-z against the (row, 8-px segment) minima
+            // span-level early-z against the minima of the row's eight 4-pixel cells: the span shrinks to
+            // the hull of the cells in which the triangle's depth bound could still win
             if (len > 0) {
-                const int g0 = xl >> 3, g1 = (xl + len - 1) >> 3;
-                const uint32_t hm = g1 - g0 <= 1 ? min(s_hz[HZ_SEG + yl * 4 + g0], s_hz[HZ_SEG + yl * 4 + g1]) : s_hz[HZ_ROW + yl];
-                if (zu < hm) len = 0;
+                const uint4 ca = *reinterpret_cast<const uint4 *>(&s_hz[HZ_C4 + yl * 8]);
+                const uint4 cb = *reinterpret_cast<const uint4 *>(&s_hz[HZ_C4 + yl * 8 + 4]);
+                uint32_t pm = (uint32_t)!(zu < ca.x) | ((uint32_t)!(zu < ca.y) << 1) | ((uint32_t)!(zu < ca.z) << 2) | ((uint32_t)!(zu < ca.w) << 3) |
+                              ((uint32_t)!(zu < cb.x) << 4) | ((uint32_t)!(zu < cb.y) << 5) | ((uint32_t)!(zu < cb.z) << 6) | ((uint32_t)!(zu < cb.w) << 7);
+                const int xr = xl + len - 1;
+                const int c0 = xl >> 2, c1 = xr >> 2;
+                pm &= (2u << c1) - (1u << c0);
+                if (pm == 0u) {
+                    len = 0;
+                } else {
+                    const int f = __builtin_ctz(pm), l = 31 - __builtin_clz(pm);
+                    const int nxl = max(xl, f << 2), nxr = min(xr, (l << 2) + 3);
+                    xl = nxl;
+                    len = nxr - nxl + 1;
+                }
             }
             // ---- spans of this window laid end to end: heads mark where each span's fragments start ----
             const unsigned long long nz = __ballot(len > 0);
@@ -606,7 +620,13 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
                     if (f.valid) {
                         if (f.rhw != f.rhw) ++n_nan;
                         const unsigned long long key = ((unsigned long long)zkey(f.rhw) << 32) | (unsigned long long)f2u(fc.y);
+#ifdef FRR_DEBUG_COUNTERS
+                        const unsigned long long old = atomicMax(&s_key[y * TILE + x], key);
+                        d_pre += __popcll(__ballot(s_ti[w][sj].zub < (uint32_t)(old >> 32)));
+                        d_win += __popcll(__ballot(key > old));
+#else
                         atomicMax(&s_key[y * TILE + x], key);
+#endif
                     }
                 }
                 seg_advance(g_lo, g_hi, qbase, qcarry);
@@ -624,6 +644,7 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
         atomicAdd(d + 0, (unsigned long long)d_tri); atomicAdd(d + 1, (unsigned long long)d_alive); atomicAdd(d + 2, (unsigned long long)d_rows);
         atomicAdd(d + 3, (unsigned long long)d_spans); atomicAdd(d + 4, (unsigned long long)d_spans_live); atomicAdd(d + 5, (unsigned long long)d_frags);
         atomicAdd(d + 6, (unsigned long long)d_fwin); atomicAdd(d + 7, (unsigned long long)d_rwin);
+        atomicAdd(d + 8, (unsigned long long)d_pre); atomicAdd(d + 9, (unsigned long long)d_win); atomicAdd(d + 10, (unsigned long long)d_rebuild);
     }
 #endif
     if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);

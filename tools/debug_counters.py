@@ -11,5 +11,5 @@ m = r.upload_mesh(tris, fr.VS_CLIP)
 for count in (True, False):
     r.set_count_fragments(count)
     r.clear(); r.draw(m, fr.PS_DEPTH)
-    print("count", count, "-> tri alive rows spans spans_live frags fwin rwin", file=sys.stderr)
+    print("count", count, "-> tri alive rows spans spans_live frags fwin rwin | zub-skippable frag-wins hiz-rebuilds", file=sys.stderr)
     r.stats()
