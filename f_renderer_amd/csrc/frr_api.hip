@@ -213,9 +213,10 @@ template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uin
     } else {
         // the span algebra needs every coordinate it touches within +-SPAN_SAFE (no i32 wrap)
         const int win_safe = a.x0 >= -SPAN_SAFE && a.y0 >= -SPAN_SAFE && a.x1 <= SPAN_SAFE && a.y1 <= SPAN_SAFE;
-        // waves per tile: 4 fills the chip when there are >= ~1024 tiles; fewer tiles (a partitioned rank,
-        // small windows) get 8 or 16 waves each so that the per-tile chain is shorter
-        int nw = grid >= 1024 ? 4 : (grid >= 512 ? 8 : 16);
+        // waves per tile: the kernel's registers allow 24 waves per CU, so the widest workgroup that still
+        // places every tile in ONE round over the 256 CUs (a partitioned rank or a small window has few
+        // tiles; more waves per tile shorten its chain)
+        int nw = grid <= 256 ? 16 : (grid <= 768 ? 8 : 4);
         if (c->raster_nw) nw = c->raster_nw;
         auto go = [&](auto count_tag, auto nw_tag) {
             constexpr bool CNT = decltype(count_tag)::value;
@@ -543,7 +544,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xBFFFFFFFu);
         if ((rc = ensure(c, c->bins2, c->bin2_cap, (size_t)ntiles * S + a.bin_cap)) != FRR_OK) return rc;
         a.bins2 = c->bins2;
-        { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix, a.slot); }
+        { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix, a.slot, getenv("FRR_BIN_STOP") ? atoi(getenv("FRR_BIN_STOP")) : 0); }
     } else {
         // fallback for frames with more tiles than fit LDS counters: global atomics
         const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(c->geom_ntris * FRR_MAX_OUT_TRIS, c->setup_cap) + 255) / 256, 2048);

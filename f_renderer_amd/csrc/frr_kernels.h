@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void k_bin(RasterArgs a)
         const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
         const int nt = ntx * nty;
         auto visit = [&](const uint4 &ent, int tx, int ty) {
-            if (ty % a.world != a.rank) return;
+            if (a.world > 1 && ty % a.world != a.rank) return;
             const int tile = ty * a.tiles_x + tx;
             if constexpr (FILL) {
                 uint32_t pos = a.tile_offsets[tile] + atomicAdd(&a.tile_cursor[tile], 1u);
@@ -560,11 +560,11 @@ __global__ __launch_bounds__(1024) void k_tile_scan(RasterArgs a, uint32_t ntile
 // scan, no CSR scan and no second launch are needed.  The global-atomic CSR path (k_bin above) remains
 // as the fallback when the tile count does not fit LDS.
 // ---------------------------------------------------------------------------------------------
-constexpr int BIN_WG = 512;
+constexpr int BIN_WG = 1024;
 constexpr int BIN_MAX_G = 256;
 constexpr uint32_t BIN_LDS_MAX_TILES = 36864; // 144 KiB of u32 counters
 
-__global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg, int slot)
+__global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg, int slot, int stop)
 {
     extern __shared__ uint32_t s_hist[]; // [ntiles]
     __shared__ uint32_t s_w[BIN_WG / 64];
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
                 const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
                 const int nt = ntx * nty;
                 auto visit = [&](const uint4 &ent, int tx, int ty) {
-                    if (ty % a.world != a.rank) return;
+                    if (a.world > 1 && ty % a.world != a.rank) return;
                     const int tile = ty * a.tiles_x + tx;
                     if constexpr (SCATTER) {
                         const uint32_t pos = atomicAdd(&s_hist[tile], 1u);
@@ -626,8 +626,10 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
             }
         }
     };
+    if (stop == 1) return;
     walk(std::false_type{});
     __syncthreads();
+    if (stop == 2) return;
     // exclusive scan over tiles, in place: thread i owns the slice [i*per, (i+1)*per)
     const uint32_t per = (ntiles + BIN_WG - 1) / BIN_WG;
     const uint32_t t0 = min(ntiles, threadIdx.x * per), t1 = min(ntiles, t0 + per);
@@ -656,6 +658,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) row[t] = s_hist[t];
     if (threadIdx.x == 0) row[ntiles] = (uint32_t)min((unsigned long long)base + total, (unsigned long long)a.bin_cap);
     __syncthreads(); // rows are read from LDS above before the cursors start moving
+    if (stop == 3) return;
     walk(std::true_type{});
 }
 
