@@ -544,7 +544,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xBFFFFFFFu);
         if ((rc = ensure(c, c->bins2, c->bin2_cap, (size_t)ntiles * S + a.bin_cap)) != FRR_OK) return rc;
         a.bins2 = c->bins2;
-        { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix, a.slot, getenv("FRR_BIN_STOP") ? atoi(getenv("FRR_BIN_STOP")) : 0); }
+        { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix, a.slot); }
     } else {
         // fallback for frames with more tiles than fit LDS counters: global atomics
         const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(c->geom_ntris * FRR_MAX_OUT_TRIS, c->setup_cap) + 255) / 256, 2048);

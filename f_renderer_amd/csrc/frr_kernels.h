@@ -564,7 +564,7 @@ constexpr int BIN_WG = 1024;
 constexpr int BIN_MAX_G = 256;
 constexpr uint32_t BIN_LDS_MAX_TILES = 36864; // 144 KiB of u32 counters
 
-__global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg, int slot, int stop)
+__global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg, int slot)
 {
     extern __shared__ uint32_t s_hist[]; // [ntiles]
     __shared__ uint32_t s_w[BIN_WG / 64];
@@ -626,10 +626,8 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
             }
         }
     };
-    if (stop == 1) return;
     walk(std::false_type{});
     __syncthreads();
-    if (stop == 2) return;
     // exclusive scan over tiles, in place: thread i owns the slice [i*per, (i+1)*per)
     const uint32_t per = (ntiles + BIN_WG - 1) / BIN_WG;
     const uint32_t t0 = min(ntiles, threadIdx.x * per), t1 = min(ntiles, t0 + per);
@@ -658,7 +656,6 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) row[t] = s_hist[t];
     if (threadIdx.x == 0) row[ntiles] = (uint32_t)min((unsigned long long)base + total, (unsigned long long)a.bin_cap);
     __syncthreads(); // rows are read from LDS above before the cursors start moving
-    if (stop == 3) return;
     walk(std::true_type{});
 }
 
