@@ -283,6 +283,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
 {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_bid, s_base, s_nclip;
+    __shared__ uint4 s_stage[GEOM_BLOCK / 64][64 * 5];    // per wave: 64 records at an 80-byte stride (see the record stores)
     __shared__ uint2 s_clist[GEOM_BLOCK];                 // (input index, output offset) of this block's clipped triangles
     __shared__ float s_cxy[GEOM_BLOCK / 64][CLIP_MAXV][2]; // per wave: clip x,y in list order
     __shared__ int32_t s_ckey[GEOM_BLOCK / 64][CLIP_MAXV];
@@ -429,11 +430,28 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
     flags |= is_top_left(px[1], py[1], px[2], py[2]) ? 0u : 4u;
     flags |= is_top_left(px[2], py[2], px[0], py[0]) ? 0u : 8u;
     { const uint2 pb = pack_pbox(px[0], py[0], px[1], py[1], px[2], py[2]); g.pbox[off] = make_uint4(pb.x, pb.y, cull_zub(rw[0], rw[1], rw[2]), 0u); }
-    uint4 *dst = reinterpret_cast<uint4 *>(g.recs + off);
-    dst[0] = make_uint4((uint32_t)px[0], (uint32_t)py[0], (uint32_t)px[1], (uint32_t)py[1]);
-    dst[1] = make_uint4((uint32_t)px[2], (uint32_t)py[2], f2u(sx[0]), f2u(sy[0]));
-    dst[2] = make_uint4(f2u(sx[1]), f2u(sy[1]), f2u(sx[2]), f2u(sy[2]));
-    dst[3] = make_uint4(f2u(rw[0]), f2u(rw[1]), f2u(rw[2]), flags);
+    const uint4 q0 = make_uint4((uint32_t)px[0], (uint32_t)py[0], (uint32_t)px[1], (uint32_t)py[1]);
+    const uint4 q1 = make_uint4((uint32_t)px[2], (uint32_t)py[2], f2u(sx[0]), f2u(sy[0]));
+    const uint4 q2 = make_uint4(f2u(sx[1]), f2u(sy[1]), f2u(sx[2]), f2u(sy[2]));
+    const uint4 q3 = make_uint4(f2u(rw[0]), f2u(rw[1]), f2u(rw[2]), flags);
+    if (__ballot(true) == ~0ull) {
+        // All 64 lanes of the wave are here: each emits exactly one triangle, so their records are
+        // consecutive in memory.  A lane-per-record store writes 16 B at a 64-B stride (64 partial-line
+        // writes per instruction, write-through); staged through LDS (80-B record stride: conflict-free
+        // b128 writes) the same 4 KB leave as four fully coalesced 1-KB stores.
+        uint4 *st = s_stage[threadIdx.x >> 6];
+        const int ln = threadIdx.x & 63;
+        st[ln * 5 + 0] = q0; st[ln * 5 + 1] = q1; st[ln * 5 + 2] = q2; st[ln * 5 + 3] = q3;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint4 *dst = reinterpret_cast<uint4 *>(g.recs + __builtin_amdgcn_readfirstlane(off));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int c = i * 64 + ln; dst[c] = st[(c >> 2) * 5 + (c & 3)]; }
+    } else {
+        uint4 *dst = reinterpret_cast<uint4 *>(g.recs + off);
+        dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
+    }
     if constexpr (K > 0) {
         float *o = g.vary + (size_t)off * (3 * K);
 #pragma unroll
