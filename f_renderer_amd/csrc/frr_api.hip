@@ -45,6 +45,8 @@ struct frr_ctx {
     Counters *cnt = nullptr;
     // geometry workspace
     uint32_t *block_sums = nullptr; size_t block_sums_cap = 0;
+    uint32_t *group_sums = nullptr; size_t group_sums_cap = 0; // two slots of 128 padded group counters (GeomArgs)
+    int geom_slot = 0;         // group_sums slot of the latest draw (alternates)
     unsigned long long *lb_status = nullptr; size_t lb_status_cap = 0;
     int bin_g = 0;             // FRR_BIN_G: override the number of binning chunks (dev)
     uint32_t ent_slot_override = 0; // FRR_ENT_SLOT: per-tile slot of bins2 in records (tests of the overflow arena)
@@ -318,7 +320,7 @@ void frr_destroy(frr_ctx *c)
     prof_collect(c);
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
-    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->lb_status, c->recs, c->vary, c->pbox,
+    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->group_sums, c->lb_status, c->recs, c->vary, c->pbox,
                     c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bins2, c->bin_matrix};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -465,6 +467,13 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
     g.cap = (uint32_t)std::min<size_t>(c->setup_cap, K > 0 ? c->vary_cap / (3 * (size_t)K) : c->setup_cap);
     g.selfsum = 0;
+    if (!c->group_sums) {
+        if ((rc = ensure(c, c->group_sums, c->group_sums_cap, (size_t)2 * 128 * GROUP_PAD)) != FRR_OK) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->group_sums, 0, (size_t)2 * 128 * GROUP_PAD * sizeof(uint32_t), c->stream));
+    }
+    c->geom_slot ^= 1;
+    g.group_sums = c->group_sums + (size_t)c->geom_slot * 128 * GROUP_PAD;
+    g.group_zero = c->group_sums + (size_t)(c->geom_slot ^ 1) * 128 * GROUP_PAD;
     g.part_rank = c->rank; g.part_world = filter ? c->world : 1; g.part_y0 = fy0; g.part_y1 = fy1;
     g.block_sums = c->block_sums; g.status = c->lb_status;
     g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;

@@ -55,12 +55,16 @@ struct DevUniforms {
     uint32_t tex_w, tex_h;
 };
 
+constexpr int GROUP_PAD = 32; // one 128-byte line per group counter: device atomics on one line serialise (~17 ns each)
+
 struct GeomArgs {
     const float *in;        // [ntris][3][NF]
     uint32_t ntris;
     uint32_t width, height; // viewport of renderer.rs:107-108
     uint32_t cap;           // setup capacity (triangles)
     int32_t selfsum;        // emit blocks sum the block counts themselves (no k_scan_blocks launch)
+    uint32_t *group_sums;   // [128 groups][GROUP_PAD]: setup triangles per group of 64 count blocks, this draw's slot ...
+    uint32_t *group_zero;   // ... and the previous draw's slot, zeroed by this draw's count kernel
     int32_t part_rank, part_world; // tile-row ownership filter (world == 1: none); only set by frr_draw,
     int32_t part_y0, part_y1;      // which knows the raster window's height range
     uint32_t *block_sums;   // [nblocks], exclusive-scanned in place (two-pass path)

@@ -83,6 +83,13 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_count(GeomArgs g, DevUnifor
     uint32_t total;
     block_excl_scan256(n, s_w, total);
     if (threadIdx.x == 0) g.block_sums[blockIdx.x] = total;
+    if (g.selfsum) {
+        // two-level sums for the emit blocks: one fire-and-forget atomic per block on its group's counter
+        // (64 blocks per counter, one cache line per counter); the other slot, used by the previous
+        // draw, is zeroed for the next one
+        if (threadIdx.x == 0 && total) atomicAdd(&g.group_sums[(blockIdx.x >> 6) * GROUP_PAD], total);
+        if (blockIdx.x == 0 && threadIdx.x < 128) g.group_zero[threadIdx.x * GROUP_PAD] = 0u;
+    }
     if (g.selfsum && blockIdx.x == 0 && threadIdx.x == 0) { // per-draw bookkeeping k_scan_blocks would do
         g.cnt->tri_base += g.cnt->n_setup;                  // previous draw's triangles precede this draw's
         g.cnt->tris_in += g.ntris;
@@ -326,8 +333,12 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
         __syncthreads();
         off += s_base;
     } else if constexpr (MODE == 2) {
+        // exclusive prefix of this block = groups before its group (<= 127 counters, threads 0..126)
+        // + the blocks before it in its own group (<= 63 block sums, threads 128..190): one load per thread
         uint32_t part = 0;
-        for (uint32_t i = threadIdx.x; i < bid; i += GEOM_BLOCK) part += g.block_sums[i];
+        const uint32_t grp = bid >> 6, inb = bid & 63u;
+        if (threadIdx.x < grp) part = g.group_sums[threadIdx.x * GROUP_PAD];
+        else if (threadIdx.x >= 128u && threadIdx.x - 128u < inb) part = g.block_sums[(grp << 6) + threadIdx.x - 128u];
         const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(part), 63);
         __syncthreads();                       // s_w was read by block_excl_scan256 above
         if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = wsum;
