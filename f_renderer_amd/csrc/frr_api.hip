@@ -50,6 +50,14 @@ struct frr_ctx {
     unsigned long long *lb_status = nullptr; size_t lb_status_cap = 0;
     int bin_g = 0;             // FRR_BIN_G: override the number of binning chunks (dev)
     uint32_t ent_slot_override = 0; // FRR_ENT_SLOT: per-tile slot of bins2 in records (tests of the overflow arena)
+    // frr_clear is deferred: the first full-window draw of the span kernel performs it inside the tile kernel
+    // (keys start from the clear depth, every pixel of the tile is written); anything else that looks at the
+    // targets or the counters first settles it with k_clear.  FRR_CLEAR=eager restores the immediate clear.
+    bool clear_eager = false;
+    bool clear_pending = false;    // targets not cleared yet
+    bool counters_pending = false; // frame counters not reset yet (the next draw's bookkeeping thread does it)
+    bool unowned_debt = false;     // partitioned ctx: the tile rows of other ranks missed a fused clear
+    uint32_t clear_rgba = 0; float clear_depth = 0.0f;
     int bin_slot = 0;          // Counters::seg_total / ent_cursor slot of the latest draw (alternates)
     bool bin_atomics = false;  // FRR_BIN=atomics: force the global-atomic binning fallback (tests)
     size_t bin_cap_init = 0;   // FRR_BIN_CAP: initial bin capacity in entries (tests of the overflow path)
@@ -197,12 +205,12 @@ template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks
         if (g.selfsum) {
             { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 2>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
         } else {
-            { ProfScope p(c, KID_SCAN_BLOCKS); hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, nblocks, g.cap, g.ntris, g.cnt); }
+            { ProfScope p(c, KID_SCAN_BLOCKS); hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, nblocks, g.cap, g.ntris, g.cnt, g.reset_frame); }
             { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 0>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
         }
     } else {
         { ProfScope p(c, KID_SCAN_BLOCKS);
-          hipLaunchKernelGGL(k_geom_begin, dim3(std::min<uint32_t>((nblocks + 255) / 256, 64)), dim3(256), 0, c->stream, g.status, nblocks, g.ntris, g.cnt); }
+          hipLaunchKernelGGL(k_geom_begin, dim3(std::min<uint32_t>((nblocks + 255) / 256, 64)), dim3(256), 0, c->stream, g.status, nblocks, g.ntris, g.cnt, g.reset_frame); }
         { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 1>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
     }
 }
@@ -280,6 +288,7 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     { const char *e = getenv("FRR_RASTER_NW"); const int v = e ? atoi(e) : 0; c->raster_nw = (v == 4 || v == 8 || v == 16) ? v : 0; }
     { const char *e = getenv("FRR_GEOM"); c->geom_twopass = !(e && strcmp(e, "lookback") == 0); c->geom_force_scan = e && strcmp(e, "scan") == 0; }
     { const char *e = getenv("FRR_BIN_G"); c->bin_g = e ? atoi(e) : 0; }
+    { const char *e = getenv("FRR_CLEAR"); c->clear_eager = e && strcmp(e, "eager") == 0; }
     { const char *e = getenv("FRR_ENT_SLOT"); c->ent_slot_override = e ? (uint32_t)atoi(e) : 0u; }
     { const char *e = getenv("FRR_BIN"); c->bin_atomics = e && strcmp(e, "atomics") == 0; }
     { const char *e = getenv("FRR_BIN_CAP"); c->bin_cap_init = e ? (size_t)atoll(e) : 0; }
@@ -329,9 +338,12 @@ void frr_destroy(frr_ctx *c)
     delete c;
 }
 
+static int settle(frr_ctx *c); // deferred frr_clear, below
+
 int frr_set_partition(frr_ctx *c, int rank, int world)
 {
     if (!c || world < 1 || rank < 0 || rank >= world) return fail(c, FRR_ERR_INVALID, "bad partition");
+    { int rc = settle(c); if (rc != FRR_OK) return rc; } // rows skipped by a fused clear are defined by the old partition
     c->rank = rank; c->world = world;
     return FRR_OK;
 }
@@ -345,6 +357,7 @@ int frr_set_count_fragments(frr_ctx *c, int enable)
 int frr_bind_targets(frr_ctx *c, void *color, void *depth, void *tri_id)
 {
     if (!c) return FRR_ERR_INVALID;
+    { int rc = settle(c); if (rc != FRR_OK) return rc; } // a pending clear belongs to the targets bound when it was issued
     c->color = color ? (uint8_t *)color : c->own_color;
     c->depth = depth ? (float *)depth : c->own_depth;
     c->tri_id = tri_id ? (uint32_t *)tri_id : c->own_tri_id;
@@ -353,6 +366,7 @@ int frr_bind_targets(frr_ctx *c, void *color, void *depth, void *tri_id)
 int frr_target_ptrs(frr_ctx *c, void **color, void **depth, void **tri_id)
 {
     if (!c) return FRR_ERR_INVALID;
+    { int rc = settle(c); if (rc != FRR_OK) return rc; } // the caller is about to look at them
     if (color) *color = c->color;
     if (depth) *depth = c->depth;
     if (tri_id) *tri_id = c->tri_id;
@@ -424,23 +438,50 @@ int frr_set_uniforms(frr_ctx *c, const frr_uniforms *u)
     return FRR_OK;
 }
 
-int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
+// the clear itself (k_clear); `counters`: also reset the frame counters
+static int clear_now(frr_ctx *c, uint32_t packed, float depth, bool counters)
 {
-    if (!c || !rgba) return FRR_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t n = c->W * c->H, n4 = n / 4;
-    uint32_t packed;
-    memcpy(&packed, rgba, 4);
     {
         ProfScope p(c, KID_CLEAR);
         uint32_t grid = std::min<uint32_t>((n4 + 255) / 256, 2048);
         hipLaunchKernelGGL(k_clear, dim3(grid ? grid : 1), dim3(256), 0, c->stream, (uint4 *)c->color, (uint4 *)c->depth,
-                           (uint4 *)c->tri_id, n4, packed, depth, c->cnt);
+                           (uint4 *)c->tri_id, n4, packed, depth, counters ? c->cnt : (Counters *)nullptr);
         if (n4 * 4 < n)
             hipLaunchKernelGGL(k_clear_tail, dim3(1), dim3(64), 0, c->stream, (uint32_t *)c->color, (uint32_t *)c->depth,
                                c->tri_id, n4 * 4, n, packed, depth);
     }
     HIP_TRY(c, hipGetLastError());
+    return FRR_OK;
+}
+
+// bring targets and counters to the state the API promises (called by everything that looks at them)
+static int settle(frr_ctx *c)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->clear_pending) {
+        int rc = clear_now(c, c->clear_rgba, c->clear_depth, c->counters_pending);
+        if (rc != FRR_OK) return rc;
+        c->clear_pending = c->counters_pending = c->unowned_debt = false;
+    } else if (c->unowned_debt) {
+        hipLaunchKernelGGL(k_clear_unowned_rows, dim3(c->H), dim3(256), 0, c->stream, (uint32_t *)c->color, (uint32_t *)c->depth,
+                           c->tri_id, c->W, c->H, c->rank, c->world, c->clear_rgba, c->clear_depth);
+        HIP_TRY(c, hipGetLastError());
+        c->unowned_debt = false;
+    }
+    return FRR_OK;
+}
+
+int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
+{
+    if (!c || !rgba) return FRR_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t packed;
+    memcpy(&packed, rgba, 4);
+    if (c->clear_eager) return clear_now(c, packed, depth, true);
+    c->clear_rgba = packed; c->clear_depth = depth;
+    c->clear_pending = c->counters_pending = true;
+    c->unowned_debt = false; // superseded: the pending clear covers every row
     return FRR_OK;
 }
 
@@ -467,6 +508,8 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
     g.cap = (uint32_t)std::min<size_t>(c->setup_cap, K > 0 ? c->vary_cap / (3 * (size_t)K) : c->setup_cap);
     g.selfsum = 0;
+    g.reset_frame = c->counters_pending ? 1 : 0;
+    c->counters_pending = false;
     if (!c->group_sums) {
         if ((rc = ensure(c, c->group_sums, c->group_sums_cap, (size_t)2 * 128 * GROUP_PAD)) != FRR_OK) return rc;
         HIP_TRY(c, hipMemsetAsync(c->group_sums, 0, (size_t)2 * 128 * GROUP_PAD * sizeof(uint32_t), c->stream));
@@ -478,7 +521,7 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     g.block_sums = c->block_sums; g.status = c->lb_status;
     g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;
     if (nt == 0) {
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, 0u, g.cap, 0u, g.cnt);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, 0u, g.cap, 0u, g.cnt, g.reset_frame);
     } else {
         switch (m.vs) {
         case FRR_VS_CLIP: launch_geometry<FRR_VS_CLIP>(c, g, nblocks); break;
@@ -514,7 +557,14 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     if ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && !c->duni.tex) return fail(c, FRR_ERR_INVALID, "no texture bound to uniforms.texture_slot");
     HIP_TRY(c, hipSetDevice(c->device));
     if (ww == 0 || wh == 0 || c->geom_ntris == 0) return FRR_OK;
+    bool fuse = false;
+    if (c->clear_pending) {
+        const bool full = x0 == 0 && y0 == 0 && x1 == (int32_t)c->W && y1 == (int32_t)c->H;
+        if (full && !c->counters_pending && !c->raster_sweep) fuse = true; // the tile kernel performs the clear
+        else { int rcs = settle(c); if (rcs != FRR_OK) return rcs; }
+    }
     RasterArgs a;
+    a.fused_clear = fuse ? 1 : 0; a.clear_rgba = c->clear_rgba; a.clear_depth = c->clear_depth;
     a.x0 = x0; a.x1 = x1; a.y0 = y0; a.y1 = y1; a.win_w = (int)ww; a.win_h = (int)wh;
     a.cstride = (int)c->W; a.dstride = x1;
     a.tiles_x = (int)((ww + TILE - 1) / TILE); a.tiles_y = (int)((wh + TILE - 1) / TILE);
@@ -573,6 +623,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         }
     }
     HIP_TRY(c, hipGetLastError());
+    if (fuse) { c->clear_pending = false; c->unowned_debt = c->world > 1; }
     return FRR_OK;
 }
 
@@ -589,13 +640,14 @@ int frr_draw(frr_ctx *c, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0
 int frr_sync(frr_ctx *c)
 {
     if (!c) return FRR_ERR_INVALID;
+    { int rc = settle(c); if (rc != FRR_OK) return rc; }
     return check_frame_counters(c, nullptr);
 }
 
 int frr_readback(frr_ctx *c, uint8_t *rgba, float *depth, uint32_t *tri_id)
 {
     if (!c) return FRR_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = settle(c); if (rc != FRR_OK) return rc; }
     const size_t bytes = (size_t)c->W * c->H * 4;
     if (rgba) HIP_TRY(c, hipMemcpyAsync(rgba, c->color, bytes, hipMemcpyDeviceToHost, c->stream));
     if (depth) HIP_TRY(c, hipMemcpyAsync(depth, c->depth, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -606,6 +658,7 @@ int frr_readback(frr_ctx *c, uint8_t *rgba, float *depth, uint32_t *tri_id)
 int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uint64_t *ntris)
 {
     if (!c || !ntris || c->geom_vs < 0) return fail(c, FRR_ERR_INVALID, "no geometry to read back");
+    { int rcs = settle(c); if (rcs != FRR_OK) return rcs; }
     Counters h;
     int rc = check_frame_counters(c, &h);
     if (rc != FRR_OK) return rc;
@@ -636,6 +689,7 @@ int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uin
 int frr_get_stats(frr_ctx *c, frr_stats *out)
 {
     if (!c || !out) return FRR_ERR_INVALID;
+    { int rc = settle(c); if (rc != FRR_OK) return rc; }
     Counters h;
     HIP_TRY(c, hipMemcpyAsync(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

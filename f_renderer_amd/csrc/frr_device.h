@@ -63,6 +63,7 @@ struct GeomArgs {
     uint32_t width, height; // viewport of renderer.rs:107-108
     uint32_t cap;           // setup capacity (triangles)
     int32_t selfsum;        // emit blocks sum the block counts themselves (no k_scan_blocks launch)
+    int32_t reset_frame;    // first draw after frr_clear: the bookkeeping thread zeroes the frame counters first
     uint32_t *group_sums;   // [128 groups][GROUP_PAD]: setup triangles per group of 64 count blocks, this draw's slot ...
     uint32_t *group_zero;   // ... and the previous draw's slot, zeroed by this draw's count kernel
     int32_t part_rank, part_world; // tile-row ownership filter (world == 1: none); only set by frr_draw,
@@ -90,6 +91,9 @@ struct RasterArgs {
     const uint32_t *seg;              // segmented binning: [nseg][ntiles+1] segment starts (+ end sentinel) into bins; nseg == 0: CSR (tile_offsets)
     uint32_t nseg;
     int32_t slot;                     // which Counters::seg_total / ent_cursor slot this draw uses
+    int32_t fused_clear;              // this draw also performs the pending frr_clear for the tiles it owns:
+    uint32_t clear_rgba;              //   keys start from clear_depth instead of the depth buffer and every pixel
+    float clear_depth;                //   of the tile is written (full-window draws of the span kernel only)
     uint32_t ent_slot;                // segmented binning: bins2 = [ntiles][ent_slot] fixed slots + an overflow arena of bin_cap records
     uint4 *bins;                      // one 16-byte cull record {tri, zub, bbox.x, bbox.y} per (triangle, tile) pair, CSR by tile
     uint4 *bins2;                     // the same records in near-first order per tile (written by the tile kernel's pre-pass)
@@ -101,6 +105,15 @@ struct RasterArgs {
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// what frr_clear does to the counters (by k_clear, or deferred to the next draw's bookkeeping thread)
+__device__ __forceinline__ void reset_frame_counters(Counters *cnt)
+{
+    cnt->n_setup = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
+    cnt->seg_total[0] = cnt->seg_total[1] = 0ull; cnt->ent_cursor[0] = cnt->ent_cursor[1] = 0u;
+    cnt->frag_covered = 0; cnt->frag_nan = 0; cnt->tris_in = 0; cnt->bin_entries_frame = 0; cnt->draws = 0;
+    for (int k = 0; k < 12; ++k) cnt->dbg[k] = 0;
+}
 
 // ---- glam pieces used by the shader table -------------------------------------
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)

@@ -22,11 +22,19 @@ __global__ __launch_bounds__(256) void k_clear(uint4 *__restrict__ color, uint4 
         depth[i] = make_uint4(db, db, db, db);
         ids[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        cnt->n_setup = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
-        cnt->seg_total[0] = cnt->seg_total[1] = 0ull; cnt->ent_cursor[0] = cnt->ent_cursor[1] = 0u;
-        cnt->frag_covered = 0; cnt->frag_nan = 0; cnt->tris_in = 0; cnt->bin_entries_frame = 0; cnt->draws = 0;
-        for (int k = 0; k < 12; ++k) cnt->dbg[k] = 0;
+    if (cnt && blockIdx.x == 0 && threadIdx.x == 0) reset_frame_counters(cnt);
+}
+// the pixel rows of the tile rows a partitioned ctx does NOT own (they are skipped by a fused clear and
+// brought up to date only when somebody looks: frr_readback, frr_target_ptrs)
+__global__ __launch_bounds__(256) void k_clear_unowned_rows(uint32_t *__restrict__ color, uint32_t *__restrict__ depth,
+                                                            uint32_t *__restrict__ ids, uint32_t W, uint32_t H, int rank,
+                                                            int world, uint32_t rgba, float d)
+{
+    const uint32_t y = blockIdx.x;
+    if (y >= H || (int)((y / TILE) % (uint32_t)world) == rank) return;
+    for (uint32_t x = threadIdx.x; x < W; x += 256u) {
+        const size_t i = (size_t)y * W + x;
+        color[i] = rgba; depth[i] = f2u(d); ids[i] = ~0u;
     }
 }
 // tail elements when W*H is not a multiple of 4
@@ -91,6 +99,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_count(GeomArgs g, DevUnifor
         if (blockIdx.x == 0 && threadIdx.x < 128) g.group_zero[threadIdx.x * GROUP_PAD] = 0u;
     }
     if (g.selfsum && blockIdx.x == 0 && threadIdx.x == 0) { // per-draw bookkeeping k_scan_blocks would do
+        if (g.reset_frame) reset_frame_counters(g.cnt);
         g.cnt->tri_base += g.cnt->n_setup;                  // previous draw's triangles precede this draw's
         g.cnt->tris_in += g.ntris;
         g.cnt->draws += 1;
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_count(GeomArgs g, DevUnifor
 
 // K1b: exclusive scan of the block sums (single workgroup), publishes n_setup, advances tri_base.
 __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *__restrict__ sums, uint32_t nblocks, uint32_t cap,
-                                                      uint32_t ntris, Counters *cnt)
+                                                      uint32_t ntris, Counters *cnt, int reset_frame)
 {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
@@ -123,6 +132,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *__restrict__ sum
     }
     if (threadIdx.x == 0) {
         uint32_t total = s_carry;
+        if (reset_frame) reset_frame_counters(cnt);
         cnt->tri_base += cnt->n_setup; // previous draw's triangles precede this draw's in the frame
         cnt->need_setup = total;
         if (total > cap) { cnt->overflow |= 1u; total = 0; }
@@ -144,10 +154,11 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *__restrict__ sum
 // by an atomic ticket, so a block only ever waits for blocks that have already started.
 constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
 
-__global__ __launch_bounds__(256) void k_geom_begin(unsigned long long *status, uint32_t nblocks, uint32_t ntris, Counters *cnt)
+__global__ __launch_bounds__(256) void k_geom_begin(unsigned long long *status, uint32_t nblocks, uint32_t ntris, Counters *cnt, int reset_frame)
 {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nblocks; i += gridDim.x * 256u) status[i] = 0ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (reset_frame) reset_frame_counters(cnt);
         cnt->tri_base += cnt->n_setup; // previous draw's triangles precede this draw's in the frame
         cnt->ticket = 0;
         cnt->tris_in += ntris;

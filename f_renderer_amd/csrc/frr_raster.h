@@ -61,8 +61,23 @@ __device__ __forceinline__ void tile_load_keys(const RasterArgs &a, const TileCt
     for (int i = threadIdx.x; i < TILE_PX; i += (int)blockDim.x) {
         const int x = i & (TILE - 1), y = i >> 5;
         unsigned long long k = oob;
-        if (x < c.tw && y < c.th) k = (unsigned long long)zkey(a.depth[(size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x)]) << 32;
+        if (x < c.tw && y < c.th)
+            k = (unsigned long long)zkey(a.fused_clear ? a.clear_depth : a.depth[(size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x)]) << 32;
         s_key[i] = k;
+    }
+}
+
+// a tile with nothing binned into it still owes the pending frr_clear (fused_clear draws)
+__device__ __forceinline__ void tile_fill_clear(const RasterArgs &a, const TileCtx &c)
+{
+    if (!a.fused_clear) return;
+    for (int i = threadIdx.x; i < TILE_PX; i += (int)blockDim.x) {
+        const int x = i & (TILE - 1), y = i >> 5;
+        if (x >= c.tw || y >= c.th) continue;
+        const size_t pi = (size_t)(c.ly0 + y) * a.cstride + (c.lx0 + x);
+        reinterpret_cast<uint32_t *>(a.color)[pi] = a.clear_rgba;
+        a.depth[pi] = a.clear_depth;
+        a.tri_id[pi] = ~0u;
     }
 }
 
@@ -76,8 +91,24 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
         const int x = i & (TILE - 1), y = i >> 5;
         if (x >= c.tw || y >= c.th) continue;
         const uint32_t id = (uint32_t)s_key[i];
+        if (a.fused_clear) { // the pending frr_clear: pixels nobody won get the clear values; colour first, a shader may overwrite it
+            const size_t pi = (size_t)(c.ly0 + y) * a.cstride + (c.lx0 + x); // full-window draw: one index for all three targets
+            if (id == 0u || PS == FRR_PS_DEPTH) reinterpret_cast<uint32_t *>(a.color)[pi] = a.clear_rgba;
+            if (id == 0u) { a.depth[pi] = a.clear_depth; a.tri_id[pi] = ~0u; }
+        }
         if (id == 0u) continue; // existing depth won (or nothing covered this pixel)
         const uint32_t t = id - 1u;
+        if constexpr (PS == FRR_PS_DEPTH) {
+            // depth only: the z key is an invertible image of rhw except that it merges -0.0 with +0.0
+            // (and NaNs are not ordered): those two cases are re-evaluated below, everything else is decoded
+            const float dz = zkey_decode((uint32_t)(s_key[i] >> 32));
+            if (dz != 0.0f && dz == dz) {
+                const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
+                a.depth[di] = dz;                                                   // :366
+                a.tri_id[di] = tri_base + t;
+                continue;
+            }
+        }
         const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + t);
         const uint4 q1 = rp[1], q2 = rp[2], q3 = rp[3];
         const int cx = c.ax0 + x, cy = c.ay0 + y;
@@ -327,7 +358,7 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
         __syncthreads();
         const uint32_t w0 = s_w4[0], w1 = s_w4[1], w2 = s_w4[2], w3 = s_w4[3];
         const uint32_t total = __builtin_amdgcn_readfirstlane((w0 + w1) + (w2 + w3)); // wave-uniform, and the compiler should know
-        if (total == 0u) return;
+        if (total == 0u) { tile_fill_clear(a, c); return; }
         if (threadIdx.x < BIN_MAX_G) {
             s_segpre[threadIdx.x] = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u) + inc - cn;
             s_segsrc[threadIdx.x] = s0;
@@ -345,6 +376,7 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
         c.beg = __builtin_amdgcn_readfirstlane(s_ebase); // this tile's range of the near-first copy (bins2)
         c.end = c.beg + total;
     } else if (c.beg >= c.end) {
+        tile_fill_clear(a, c);
         return;
     }
     // k-th record of this tile, k in [0, c.end - c.beg)

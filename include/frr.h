@@ -133,7 +133,13 @@ int frr_vs_num_varyings(int vs_id);
 
 /* ---- frame ------------------------------------------------------------------------------- */
 
-/* frame_buffer.fill(rgba) + depth_buffer.fill(depth)  (phong.rs:316-317, renderer.rs:485-494) */
+/* frame_buffer.fill(rgba) + depth_buffer.fill(depth)  (phong.rs:316-317, renderer.rs:485-494).
+ * Also resets the per-frame statistics and the setup list of a preceding frr_geometry.  The device
+ * work is deferred: the next full-framebuffer frr_raster / frr_draw performs the clear inside its tile
+ * kernel; every other call that can observe the targets or the statistics (frr_readback, frr_sync,
+ * frr_get_stats, frr_target_ptrs, frr_bind_targets, a sub-window raster) settles it first, so the
+ * observable behaviour is that of an immediate clear.  (FRR_CLEAR=eager in the environment makes it
+ * immediate.) */
 int frr_clear(frr_ctx *ctx, const uint8_t rgba[4], float depth);
 
 /* Loop A (phong.rs:321-331): Renderer::geometry_processing over every input triangle of `mesh`,
