@@ -47,7 +47,7 @@ struct frr_ctx {
     uint32_t *block_sums = nullptr; size_t block_sums_cap = 0;
     uint32_t *group_sums = nullptr; size_t group_sums_cap = 0; // two slots of 128 padded group counters (GeomArgs)
     int geom_slot = 0;         // group_sums slot of the latest draw (alternates)
-    unsigned long long *lb_status = nullptr; size_t lb_status_cap = 0;
+    uint2 *clip_list = nullptr; size_t clip_list_cap = 0;     // clipped triangles of the current draw (k_geom_count -> k_geom_emit)
     int bin_g = 0;             // FRR_BIN_G: override the number of binning chunks (dev)
     uint32_t ent_slot_override = 0; // FRR_ENT_SLOT: per-tile slot of bins2 in records (tests of the overflow arena)
     // frr_clear is deferred: the first full-window draw of the span kernel performs it inside the tile kernel
@@ -62,7 +62,6 @@ struct frr_ctx {
     bool bin_atomics = false;  // FRR_BIN=atomics: force the global-atomic binning fallback (tests)
     size_t bin_cap_init = 0;   // FRR_BIN_CAP: initial bin capacity in entries (tests of the overflow path)
     bool geom_force_scan = false; // FRR_GEOM=scan: always launch k_scan_blocks (the path used beyond 8192 blocks)
-    bool geom_twopass = true;  // default; FRR_GEOM=lookback selects the single-pass look-back kernel (slower on MI355X: 79 vs 57 us at 1M tris)
     RasterRec *recs = nullptr; size_t setup_cap = 0; size_t setup_hint = 0;
     float *vary = nullptr; size_t vary_cap = 0; // floats
     uint4 *pbox = nullptr; size_t pbox_cap = 0;
@@ -199,19 +198,13 @@ int check_frame_counters(frr_ctx *c, Counters *host)
 
 template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks)
 {
-    if (c->geom_twopass) {
-        g.selfsum = nblocks <= 8192 && !c->geom_force_scan; // each emit block then sums <= 8192 block counts itself
-        { ProfScope p(c, KID_GEOM_COUNT); hipLaunchKernelGGL(k_geom_count<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
-        if (g.selfsum) {
-            { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 2>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
-        } else {
-            { ProfScope p(c, KID_SCAN_BLOCKS); hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, nblocks, g.cap, g.ntris, g.cnt, g.reset_frame); }
-            { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 0>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
-        }
+    g.selfsum = nblocks <= 8192 && !c->geom_force_scan; // emit blocks then derive their prefix from the two-level sums themselves
+    { ProfScope p(c, KID_GEOM_COUNT); hipLaunchKernelGGL(k_geom_count<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
+    if (g.selfsum) {
+        { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 2>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
     } else {
-        { ProfScope p(c, KID_SCAN_BLOCKS);
-          hipLaunchKernelGGL(k_geom_begin, dim3(std::min<uint32_t>((nblocks + 255) / 256, 64)), dim3(256), 0, c->stream, g.status, nblocks, g.ntris, g.cnt, g.reset_frame); }
-        { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 1>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
+        { ProfScope p(c, KID_SCAN_BLOCKS); hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, nblocks, g.cap, g.ntris, g.cnt, g.reset_frame); }
+        { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 0>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
     }
 }
 
@@ -286,7 +279,7 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     c->device = device; c->W = width; c->H = height;
     { const char *e = getenv("FRR_RASTER"); c->raster_sweep = e && strcmp(e, "sweep") == 0; }
     { const char *e = getenv("FRR_RASTER_NW"); const int v = e ? atoi(e) : 0; c->raster_nw = (v == 4 || v == 8 || v == 16) ? v : 0; }
-    { const char *e = getenv("FRR_GEOM"); c->geom_twopass = !(e && strcmp(e, "lookback") == 0); c->geom_force_scan = e && strcmp(e, "scan") == 0; }
+    { const char *e = getenv("FRR_GEOM"); c->geom_force_scan = e && strcmp(e, "scan") == 0; }
     { const char *e = getenv("FRR_BIN_G"); c->bin_g = e ? atoi(e) : 0; }
     { const char *e = getenv("FRR_CLEAR"); c->clear_eager = e && strcmp(e, "eager") == 0; }
     { const char *e = getenv("FRR_ENT_SLOT"); c->ent_slot_override = e ? (uint32_t)atoi(e) : 0u; }
@@ -329,7 +322,7 @@ void frr_destroy(frr_ctx *c)
     prof_collect(c);
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
-    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->group_sums, c->lb_status, c->recs, c->vary, c->pbox,
+    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->group_sums, c->clip_list, c->recs, c->vary, c->pbox,
                     c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bins2, c->bin_matrix};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -500,7 +493,7 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     const uint32_t nblocks = (uint32_t)((nt + GEOM_BLOCK - 1) / GEOM_BLOCK);
     int rc;
     if ((rc = ensure(c, c->block_sums, c->block_sums_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
-    if ((rc = ensure(c, c->lb_status, c->lb_status_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
+    if ((rc = ensure(c, c->clip_list, c->clip_list_cap, (size_t)std::max<uint64_t>(nt, 1))) != FRR_OK) return rc;
     if ((rc = ensure(c, c->recs, c->setup_cap, (size_t)cap)) != FRR_OK) return rc;
     if ((rc = ensure(c, c->pbox, c->pbox_cap, c->setup_cap)) != FRR_OK) return rc;
     if (K > 0 && (rc = ensure(c, c->vary, c->vary_cap, (size_t)c->setup_cap * 3 * 8 /* K <= 8 in the shader table */)) != FRR_OK) return rc;
@@ -518,7 +511,7 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     g.group_sums = c->group_sums + (size_t)c->geom_slot * 128 * GROUP_PAD;
     g.group_zero = c->group_sums + (size_t)(c->geom_slot ^ 1) * 128 * GROUP_PAD;
     g.part_rank = c->rank; g.part_world = filter ? c->world : 1; g.part_y0 = fy0; g.part_y1 = fy1;
-    g.block_sums = c->block_sums; g.status = c->lb_status;
+    g.block_sums = c->block_sums; g.clip_list = c->clip_list; g.cslot = c->geom_slot;
     g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;
     if (nt == 0) {
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, 0u, g.cap, 0u, g.cnt, g.reset_frame);

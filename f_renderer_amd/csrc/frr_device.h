@@ -36,9 +36,10 @@ struct Counters {
     uint64_t bin_entries_frame;
     uint32_t draws;
     uint32_t need_setup;    // setup triangles the current draw needs (valid even on overflow)
-    uint32_t ticket;        // dynamic block ids of the single-pass geometry kernel
+    uint32_t reserved1;
     uint32_t pad0;
     unsigned long long seg_total[2]; // segmented binning: entries reserved by the current / previous draw (slots alternate per draw)
+    uint32_t clip_n[2];              // clipped triangles listed by the current / previous draw's k_geom_count (slots alternate)
     uint32_t ent_cursor[2];          // tile kernel: space handed out in the overflow arena of bins2 (same slots)
     unsigned long long dbg[12]; // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py)
 };
@@ -68,8 +69,9 @@ struct GeomArgs {
     uint32_t *group_zero;   // ... and the previous draw's slot, zeroed by this draw's count kernel
     int32_t part_rank, part_world; // tile-row ownership filter (world == 1: none); only set by frr_draw,
     int32_t part_y0, part_y1;      // which knows the raster window's height range
-    uint32_t *block_sums;   // [nblocks], exclusive-scanned in place (two-pass path)
-    unsigned long long *status; // [nblocks] look-back status words (single-pass path)
+    uint32_t *block_sums;   // [nblocks] setup triangles per count block; exclusive-scanned in place by k_scan_blocks (MODE 0)
+    uint2 *clip_list;       // [<= ntris] clipped triangles of this draw: (input index, offset within its block | fan size << 16)
+    int32_t cslot;          // Counters::clip_n slot of this draw
     RasterRec *recs;
     float *vary;
     uint4 *pbox;            // per setup triangle, the binning input: {minx|miny<<16, maxx|maxy<<16 (i16 pixel bbox of spi), zkey of an upper bound of |rhw|, 0}
@@ -207,7 +209,7 @@ constexpr float CLIP_EPSILON = 1.0e-5f; // renderer.rs:44
 
 // Number of triangles geometry_processing returns for clip positions pos[3][4]:
 // 0 (None, :117-119), 1 (all inside), else n-2 with n = 3 + kept intersections (:150-171).
-// `clipped` tells the caller the slow path is needed.
+// `clipped` tells the caller the slow path is needed (at least one intersection vertex was kept).
 __device__ __forceinline__ uint32_t classify(const float pos[3][4], bool &clipped)
 {
     clipped = false;
@@ -230,6 +232,9 @@ __device__ __forceinline__ uint32_t classify(const float pos[3][4], bool &clippe
     pair(pos[0], pos[1], in0 ^ in1);
     pair(pos[0], pos[2], in0 ^ in2);
     pair(pos[1], pos[2], in1 ^ in2);
+    // No intersection kept (e.g. all three vertices beyond the same plane): the reference's vertex list is
+    // just the three originals, exactly the all-inside case -- one code path there, the fast path here.
+    clipped = n != 3u;
     return n - 2;
 }
 

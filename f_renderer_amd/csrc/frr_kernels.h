@@ -77,20 +77,35 @@ template <int VS>
 __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_count(GeomArgs g, DevUniforms u)
 {
     __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_nclip, s_cbase;
     constexpr int NF = VSInfo<VS>::NF;
     const uint32_t t = blockIdx.x * GEOM_BLOCK + threadIdx.x;
     uint32_t n = 0;
+    bool clipped = false;
+    if (threadIdx.x == 0) s_nclip = 0; // ordered before its use by the barrier inside block_excl_scan256
     if (t < g.ntris) {
         float pos[3][4];
         const float *in = g.in + (size_t)t * (3 * NF);
 #pragma unroll
         for (int v = 0; v < 3; ++v) run_vs<VS, false>(u, in + v * NF, pos[v], nullptr);
-        bool clipped;
         n = classify(pos, clipped);
     }
     uint32_t total;
-    block_excl_scan256(n, s_w, total);
+    const uint32_t off_local = block_excl_scan256(n, s_w, total);
     if (threadIdx.x == 0) g.block_sums[blockIdx.x] = total;
+    // clipped triangles that emit anything go on the draw's global list: (input index, offset within the
+    // block | fan size << 16); one returning atomic per block that has any
+    const bool listed = clipped && n != 0u;
+    uint32_t crank = 0;
+    if (listed) crank = atomicAdd(&s_nclip, 1u);
+    __syncthreads();
+    const uint32_t nclip = s_nclip;
+    if (nclip) {
+        if (threadIdx.x == 0) s_cbase = atomicAdd(&g.cnt->clip_n[g.cslot], nclip);
+        __syncthreads();
+        if (listed) g.clip_list[s_cbase + crank] = make_uint2(t, off_local | (n << 16));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) g.cnt->clip_n[g.cslot ^ 1] = 0u; // the previous draw's list, for the next draw
     if (g.selfsum) {
         // two-level sums for the emit blocks: one fire-and-forget atomic per block on its group's counter
         // (64 blocks per counter, one cache line per counter); the other slot, used by the previous
@@ -146,56 +161,9 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *__restrict__ sum
 // K1c geometry emit, unclipped fast path: renderer.rs:113-148 (VS, reject, classify),
 // :180-218 (centroid + stable angle sort of 3), :220-235 (divide, viewport, snap), :237-243,
 // then the per-triangle prologue of rasterization (:300-320) so the record is ready to scan.
-// Clipped triangles are collected per block and handled by clip_triangle_wave (one wave each).
-// ---------------------------------------------------------------------------------------------
-// Single-pass variant (LOOKBACK): the block offsets come from a decoupled look-back scan over
-// 64-bit status words {flag:2, value:62} (flag 1 = block aggregate, 2 = inclusive prefix), so the
-// inputs are read once and k_geom_count / k_scan_blocks are not launched.  Block ids are handed out
-// by an atomic ticket, so a block only ever waits for blocks that have already started.
-constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
-
-__global__ __launch_bounds__(256) void k_geom_begin(unsigned long long *status, uint32_t nblocks, uint32_t ntris, Counters *cnt, int reset_frame)
-{
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nblocks; i += gridDim.x * 256u) status[i] = 0ull;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (reset_frame) reset_frame_counters(cnt);
-        cnt->tri_base += cnt->n_setup; // previous draw's triangles precede this draw's in the frame
-        cnt->ticket = 0;
-        cnt->tris_in += ntris;
-        cnt->draws += 1;
-    }
-}
-
-// wave 0 of block b: exclusive prefix of the block totals; publishes this block's status
-__device__ __forceinline__ uint32_t lookback_exclusive(unsigned long long *st, uint32_t b, uint32_t my_total, int lane)
-{
-    if (b == 0) {
-        if (lane == 0) __hip_atomic_store(&st[0], LB_PREFIX | my_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-    }
-    if (lane == 0) __hip_atomic_store(&st[b], LB_AGG | my_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t excl = 0;
-    int j = (int)b - 1; // nearest predecessor not yet accounted for
-    for (;;) {
-        const int idx = j - lane;
-        // the virtual block -1 carries prefix 0
-        const unsigned long long v = idx >= 0 ? __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;
-        const uint32_t flag = (uint32_t)(v >> 62);
-        const unsigned long long m_empty = __ballot(flag == 0u), m_prefix = __ballot(flag == 2u);
-        const int first_prefix = m_prefix ? __builtin_ctzll(m_prefix) : 64;
-        const int first_empty = m_empty ? __builtin_ctzll(m_empty) : 64;
-        const bool done = first_prefix < first_empty;              // a prefix is reachable through aggregates only
-        const int take = done ? first_prefix + 1 : first_empty;    // lanes [0, take) are usable now
-        const uint32_t part = wave_incl_scan(lane < take ? (uint32_t)(v & LB_VALUE) : 0u);
-        excl += (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
-        if (done) break;
-        j -= take;
-        if (take == 0) __builtin_amdgcn_s_sleep(2);
-    }
-    if (lane == 0) __hip_atomic_store(&st[b], LB_PREFIX | (unsigned long long)(excl + my_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return excl;
-}
-
+// Clipped triangles were listed by k_geom_count (GeomArgs::clip_list); after its own triangles every
+// wave of the grid takes its share of that list (clip_triangle_wave: one wave per clipped triangle), so
+// a mesh whose clipped triangles are clustered (a screen-filling sheet) does not serialise on a few blocks.
 // ---------------------------------------------------------------------------------------------
 // Clipped triangles: the reference's quirky clipper (renderer.rs:150-171: one intersection per
 // (edge, plane) with differing in/out flags, outside vertices kept), centroid + stable angle sort of
@@ -294,27 +262,18 @@ __device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevU
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // staging is reused by the wave's next triangle
 }
 
-// MODE 0: block_sums were exclusive-scanned by k_scan_blocks; MODE 1 (LOOKBACK): single pass, see above;
-// MODE 2: every block sums block_sums[0 .. b) itself (<= 8192 blocks: cheaper than a scan launch).
+// MODE 0: block_sums were exclusive-scanned by k_scan_blocks;
+// MODE 2: every block derives its prefix from the two-level sums itself (<= 8192 blocks: cheaper than a scan launch).
 template <int VS, int MODE>
 __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniforms u)
 {
     __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_bid, s_base, s_nclip;
     __shared__ uint4 s_stage[GEOM_BLOCK / 64][64 * 5];    // per wave: 64 records at an 80-byte stride (see the record stores)
-    __shared__ uint2 s_clist[GEOM_BLOCK];                 // (input index, output offset) of this block's clipped triangles
     __shared__ float s_cxy[GEOM_BLOCK / 64][CLIP_MAXV][2]; // per wave: clip x,y in list order
     __shared__ int32_t s_ckey[GEOM_BLOCK / 64][CLIP_MAXV];
     __shared__ float s_cv[GEOM_BLOCK / 64][CLIP_MAXV][7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)];
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K;
-    constexpr bool LOOKBACK = MODE == 1;
-    uint32_t bid = blockIdx.x;
-    if (threadIdx.x == 0) s_nclip = 0; // ordered before its first use by the barrier inside block_excl_scan256
-    if constexpr (LOOKBACK) {
-        if (threadIdx.x == 0) s_bid = atomicAdd(&g.cnt->ticket, 1u);
-        __syncthreads();
-        bid = s_bid;
-    }
+    const uint32_t bid = blockIdx.x;
     const uint32_t t = bid * GEOM_BLOCK + threadIdx.x;
     float pos[3][4];
     float ctx[3][K > 0 ? K : 1];
@@ -328,22 +287,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
     }
     uint32_t total;
     uint32_t off = block_excl_scan256(n, s_w, total);
-    if constexpr (LOOKBACK) {
-        if (threadIdx.x < 64) {
-            const uint32_t excl = lookback_exclusive(g.status, bid, total, (int)threadIdx.x);
-            if (threadIdx.x == 0) {
-                s_base = excl;
-                if (bid == gridDim.x - 1) { // the last block knows the grand total
-                    const uint32_t all = excl + total;
-                    g.cnt->need_setup = all;
-                    if (all > g.cap) atomicOr(&g.cnt->overflow, 1u);
-                    g.cnt->n_setup = all > g.cap ? 0u : all;
-                }
-            }
-        }
-        __syncthreads();
-        off += s_base;
-    } else if constexpr (MODE == 2) {
+    if constexpr (MODE == 2) {
         // exclusive prefix of this block = groups before its group (<= 127 counters, threads 0..126)
         // + the blocks before it in its own group (<= 63 block sums, threads 128..190): one load per thread
         uint32_t part = 0;
@@ -367,8 +311,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
     }
     // nothing to emit (None / dropped) or capacity overflow (the frame is flagged invalid)
     const bool emit_ok = n != 0 && (MODE != 0 ? off + n <= g.cap : g.cnt->n_setup != 0u);
-    if (emit_ok && clipped) s_clist[atomicAdd(&s_nclip, 1u)] = make_uint2(t, off); // handled below, by a whole wave
-    if (emit_ok && !clipped) {
+    if (emit_ok && !clipped) { // (clipped triangles: the draw's list, below)
     const float fw = (float)g.width, fh = (float)g.height;
     const ScreenVtx s0 = to_screen(pos[0], fw, fh), s1 = to_screen(pos[1], fw, fh), s2 = to_screen(pos[2], fw, fh);
     // Multi-GPU: a rank that owns none of the tile rows this triangle's bbox touches never reads its
@@ -483,13 +426,30 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
     }
     } // owned
     } // fast path
-    __syncthreads();
-    // clipped triangles of this block: one wave per triangle, lanes = candidate vertices
-    const uint32_t nclip = s_nclip;
+    // clipped triangles of the whole draw (listed by k_geom_count): wave q of the grid takes entries
+    // q, q + #waves, ...; one wave per triangle, lanes = candidate vertices
+    const uint32_t nclip = g.cnt->clip_n[g.cslot];
     if (nclip) {
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        for (uint32_t e = (uint32_t)w; e < nclip; e += GEOM_BLOCK / 64)
-            clip_triangle_wave<VS>(g, u, s_clist[e].x, s_clist[e].y, lane, s_cxy[w], s_ckey[w], s_cv[w]);
+        const uint32_t nwaves = gridDim.x * (GEOM_BLOCK / 64);
+        for (uint32_t e = bid * (GEOM_BLOCK / 64) + (uint32_t)w; e < nclip; e += nwaves) {
+            const uint2 en = g.clip_list[e];
+            const uint32_t ct = en.x, cn = en.y >> 16, cb = ct / GEOM_BLOCK;
+            uint32_t base;
+            if constexpr (MODE == 2) {
+                const uint32_t grp = cb >> 6, inb = cb & 63u;
+                uint32_t part = 0;
+                if ((uint32_t)lane < grp) part += g.group_sums[lane * GROUP_PAD];
+                if ((uint32_t)lane + 64u < grp) part += g.group_sums[(lane + 64) * GROUP_PAD];
+                if ((uint32_t)lane < inb) part += g.block_sums[(grp << 6) + lane];
+                base = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(part), 63);
+            } else {
+                base = g.block_sums[cb];
+            }
+            const uint32_t coff = base + (en.y & 0xFFFFu);
+            const bool ok = MODE != 0 ? coff + cn <= g.cap : g.cnt->n_setup != 0u;
+            if (ok) clip_triangle_wave<VS>(g, u, ct, coff, lane, s_cxy[w], s_ckey[w], s_cv[w]);
+        }
     }
 }
 

@@ -238,3 +238,35 @@ def test_hot_tiles_use_the_overflow_arena(oracle, monkeypatch, slot):
         np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
         assert r.stats()["frag_covered"] == f.counters.frag_covered
         assert r.stats()["bin_entries"] > 0
+
+
+def test_clustered_clipped_triangles(oracle):
+    """Every triangle of the mesh is clipped (a screen-filling sheet reaching past the frustum): the
+    clipped-triangle list built by k_geom_count is shared by all waves of k_geom_emit."""
+    import f_renderer_amd as fr
+    W, H, n = 256, 160, 48
+    xs = np.linspace(-1.6, 1.6, n + 1, dtype=np.float32)
+    tris = []
+    for i in range(n):
+        for sgn in (1.0, -1.0):                                   # a strip above and one below the frustum edge
+            y0, y1 = np.float32(0.7 * sgn), np.float32(1.5 * sgn)
+            w = np.float32(1.0 + 0.01 * i)
+            a = [xs[i] * w, y0 * w, 0.3 * w, w]; b = [xs[i + 1] * w, y0 * w, 0.3 * w, w]
+            c = [xs[i] * w, y1 * w, 0.3 * w, w]; d = [xs[i + 1] * w, y1 * w, 0.3 * w, w]
+            tris += [[a, b, c], [b, d, c]]
+    tris = np.asarray(tris, np.float32)
+    f = oracle.Frame(W, H)
+    f.clear()
+    setup = f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms(), keep_setup=True)
+    assert setup.shape[0] > len(tris)                             # fans were emitted
+    r = fr.Renderer(W, H)
+    r.clear()
+    r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
+    g = r.setup_triangles()
+    assert g.shape[0] == setup.shape[0]
+    np.testing.assert_array_equal(g["spi"], setup["spi"])
+    np.testing.assert_array_equal(g["rhw"].view(np.uint32), setup["rhw"].view(np.uint32))
+    if not f.counters.frag_nan:
+        _, d, t = r.readback()
+        np.testing.assert_array_equal(t, f.tri_id)
+        np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))

@@ -1,12 +1,12 @@
-"""Alternate kernel paths kept for A/B and as fallbacks must produce the same bits as the defaults:
-FRR_GEOM=lookback (single-pass decoupled look-back geometry kernel instead of count + scan + emit)."""
+"""Alternate kernel paths kept as fallbacks must produce the same bits as the defaults: FRR_GEOM=scan
+(k_scan_blocks between count and emit, the path of meshes with more than 8192 count blocks)."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("geom", ["lookback", "scan", "default"])
+@pytest.mark.parametrize("geom", ["scan", "default"])
 def test_geometry_paths_agree_with_oracle(oracle, geom, monkeypatch):
     import f_renderer_amd as fr
     from f_renderer_amd import scenes
@@ -32,11 +32,13 @@ def test_geometry_paths_agree_with_oracle(oracle, geom, monkeypatch):
     assert r.stats()["tris_setup"] == f.counters.tris_setup
 
 
-def test_repeated_draws_lookback_state_resets(oracle, monkeypatch):
-    """The look-back status words and the block ticket are re-armed by every draw."""
+@pytest.mark.parametrize("geom", ["scan", "default"])
+def test_repeated_draws_per_draw_state_resets(oracle, monkeypatch, geom):
+    """Group sums, the clipped-triangle list and the binning counters alternate slots per draw."""
     import f_renderer_amd as fr
     from f_renderer_amd import scenes
-    monkeypatch.setenv("FRR_GEOM", "lookback")
+    if geom != "default":
+        monkeypatch.setenv("FRR_GEOM", geom)
     W, H = 256, 144
     a = scenes.random_clip_triangles(9000, W, H, seed=12)
     b = scenes.random_clip_triangles(3000, W, H, seed=13, spread=1.3)

@@ -40,9 +40,12 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--skip-oracle", action="store_true")
     ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--only", default=None, help="run only the configs whose name contains this string")
     args = ap.parse_args()
     rows = []
     for cfg in configs():
+        if args.only and args.only not in cfg["name"]:
+            continue
         W, H, mesh = cfg["W"], cfg["H"], cfg["mesh"]
         vs, ps = getattr(fr, "VS_" + cfg["vs"]), getattr(fr, "PS_" + cfg["ps"])
         r = fr.Renderer(W, H)
@@ -74,6 +77,16 @@ def main():
         row = dict(config=cfg["name"], width=W, height=H, triangles=ntris, setup_triangles=st["tris_setup"],
                    covered_fragments=st["frag_covered"], gpu_ms=round(ms, 4), gpu_mtri_s=round(ntris / ms / 1e3, 2),
                    gpu_mfrag_s=round(st["frag_covered"] / ms / 1e3, 1), earlyz_output_identical=same_fast)
+        r.profile_enable(True); r.profile_reset()
+        for _ in range(5):
+            r.clear(); r.draw(m, ps)
+        kus = {}
+        for k in fr.Renderer.KERNELS:
+            t, cnt = r.profile_get(k)
+            if cnt:
+                kus[k] = round(t / cnt * 1e3, 1)
+        r.profile_enable(False)
+        row.update(bin_entries=st["bin_entries"], kernels_us=kus)
         if not args.skip_oracle:
             from oracle import cref
             okw = {}
