@@ -42,6 +42,11 @@ def parse_args():
     ap.add_argument("--workload", default="random_1M_tris_1920x1080_depth", choices=sorted(WORKLOADS))
     ap.add_argument("--force-dist", action="store_true",
                     help="dev: initialise RCCL and run the band gather even with one rank (exercises the N>1 code path)")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="N > 1: wait for each frame's gather before rendering the next one (default: the gather of "
+                         "frame i overlaps the rendering of frame i+1 into a second target set)")
+    ap.add_argument("--gather-rows-div", type=int, default=1,
+                    help="dev, with --force-dist on one rank: gather only 1/D of the rows (a band of the size a rank of D would send)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0,
                     help="approximate CPU time budget of the oracle baseline leg (rank 0, N=1 only); 0 disables")
     return ap.parse_args()
@@ -122,33 +127,58 @@ def main():
         # rows are padded to a whole number of tile rows per rank so owned bands are one strided view
         from f_renderer_amd.multigpu import BandGather, band_layout
         _, _, HP = band_layout(H, world)
-        color = torch.zeros((HP, W), dtype=torch.int32, device="cuda")
-        depth = torch.zeros((HP, W), dtype=torch.float32, device="cuda")
-        tri_id = torch.full((HP, W), -1, dtype=torch.int32, device="cuda")
-        r.bind_targets(color.data_ptr(), depth.data_ptr(), tri_id.data_ptr())
+        # two target sets: frame i renders into set i % 2 while the gather of frame i-1 (other set) is in flight
+        nsets = 2 if dist is not None else 1
+        color = [torch.zeros((HP, W), dtype=torch.int32, device="cuda") for _ in range(nsets)]
+        depth = [torch.zeros((HP, W), dtype=torch.float32, device="cuda") for _ in range(nsets)]
+        tri_id = [torch.full((HP, W), -1, dtype=torch.int32, device="cuda") for _ in range(nsets)]
+        r.bind_targets(color[0].data_ptr(), depth[0].data_ptr(), tri_id[0].data_ptr())
         r.set_partition(rank, world)
         dev_in = torch.from_numpy(tris).to("cuda")  # resident in HBM before timing
         mesh = r.bind_mesh_device(dev_in.data_ptr(), ntris, fr.VS_CLIP, keepalive=dev_in)
-        gather = BandGather(H, W, torch.float32, "cuda", rank, world) if dist is not None else None
+        gh = H // max(1, args.gather_rows_div) if world == 1 else H
+        gathers = [BandGather(gh, W, torch.float32, "cuda", rank, world) for _ in range(nsets)] if dist is not None else None
+        ghp = band_layout(gh, world)[2]
+        inflight = [None] * nsets
         final = None
+        frame_no = 0
+
+        def drain():
+            nonlocal final
+            for s in range(nsets):
+                if inflight[s] is not None:
+                    final = gathers[s].finish(inflight[s])
+                    inflight[s] = None
 
         def step():
-            nonlocal final
+            nonlocal final, frame_no
+            s = frame_no % nsets
+            frame_no += 1
+            if gathers is not None:
+                if inflight[s] is not None:            # the gather that last read this target set must be done
+                    final = gathers[s].finish(inflight[s])
+                r.bind_targets(color[s].data_ptr(), depth[s].data_ptr(), tri_id[s].data_ptr())
             r.clear((30, 30, 30, 255), 0.0)
             r.draw(mesh, fr.PS_DEPTH)
-            if gather is not None:
-                final = gather(depth)   # owned bands -> ONE RCCL gather to rank 0 (final image only)
+            if gathers is not None:
+                # owned bands -> ONE RCCL gather to rank 0 (final image only), overlapped with the next frame
+                inflight[s] = gathers[s].start(depth[s][:ghp])
+                if args.sync_gather:
+                    final = gathers[s].finish(inflight[s])
+                    inflight[s] = None
 
         # one counted frame: the exact covered-fragment count of this rank's tiles (the Mfrag/s
         # numerator).  The statistic is then switched off: maintaining it forbids the tile kernel's
         # whole-triangle early-z (outputs are identical either way, tests/test_gpu_earlyz.py).
         r.set_count_fragments(True)
         step()
+        drain()
         r.sync()
         counted = r.stats()
         r.set_count_fragments(False)
         for _ in range(args.warmup):
             step()
+        drain()
         r.sync()
         stats = r.stats()
         if stats["overflow"] or counted["overflow"]:
@@ -162,6 +192,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        drain()                      # every frame's image has reached rank 0 inside the timed region
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -173,10 +204,10 @@ def main():
 
         # multi-GPU image check on rank 0: gathered image == what a single full render would hold
         image_ok = None
-        if gather is not None and rank == 0:
+        if gathers is not None and rank == 0:
             # every pixel of the gathered depth image must come from its owner's render (clear value 0 or a
             # positive 1/w): finite and non-negative everywhere, and not all background
-            img = final[:H]
+            img = final[:gh]
             image_ok = bool(torch.isfinite(img).all().item() and (img >= 0).all().item() and (img > 0).any().item())
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

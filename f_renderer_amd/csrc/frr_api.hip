@@ -616,7 +616,12 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         }
     }
     HIP_TRY(c, hipGetLastError());
-    if (fuse) { c->clear_pending = false; c->unowned_debt = c->world > 1; }
+    if (fuse) {
+        c->clear_pending = false;
+        // the tile rows of other ranks missed this clear: owed to the ctx's own targets (frr_readback shows the
+        // whole image); caller-bound targets of a partitioned ctx only ever have their owned rows defined
+        c->unowned_debt = c->world > 1 && c->color == c->own_color && c->depth == c->own_depth && c->tri_id == c->own_tri_id;
+    }
     return FRR_OK;
 }
 

@@ -48,6 +48,22 @@ class BandGather:
         else:
             self.gbuf, self.gathered, self.final = None, None, None
 
+    def start(self, local_image, group=None):
+        """Asynchronous form: stages the owned bands and launches the gather without waiting for it, so that the
+        next frame (rendered into ANOTHER target set) overlaps the exchange.  Returns a handle for finish()."""
+        import torch.distributed as dist
+        self.band.copy_(owned_view(local_image, self.rank, self.world))
+        return dist.gather(self.band, self.gathered, dst=self.dst, group=group, async_op=True)
+
+    def finish(self, handle):
+        """Waits (on the current stream) for a gather started with start() and interleaves the bands on dst."""
+        handle.wait()
+        if self.rank == self.dst:
+            v = self.final.view(self.rows_per_rank, self.world, TILE, *self.final.shape[1:])
+            v.copy_(self.gbuf.transpose(0, 1))
+            return self.final
+        return None
+
     def __call__(self, local_image, group=None):
         """local_image: this rank's padded image [HP, W, ...] (only its owned bands are meaningful)."""
         import torch.distributed as dist

@@ -112,7 +112,10 @@ int frr_set_partition(frr_ctx *ctx, int rank, int world);
 int frr_set_count_fragments(frr_ctx *ctx, int enable);
 
 /* Use caller-owned DEVICE buffers (e.g. torch tensors) as the frame targets instead of the
- * internally allocated ones; any may be NULL to keep the internal one. */
+ * internally allocated ones; any may be NULL to keep the internal one.  On a partitioned ctx
+ * (frr_set_partition, world > 1) only the tile rows the rank owns are defined in caller-owned targets
+ * (a clear that was performed inside a draw never touches the other ranks' rows); the ctx's own targets
+ * are brought up to date in full whenever they are read back. */
 int frr_bind_targets(frr_ctx *ctx, void *color_rgba8, void *depth_f32, void *tri_id_u32);
 int frr_target_ptrs(frr_ctx *ctx, void **color_rgba8, void **depth_f32, void **tri_id_u32);
 

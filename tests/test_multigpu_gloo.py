@@ -32,7 +32,19 @@ def _worker(rank, world, port, H, W, full_np, out_path):
     g = BandGather(H, W, torch.float32, "cpu", rank, world)
     for _ in range(2):                                         # twice: the staging buffers are reused per frame
         final = g(local)
+    # bench.py's pipelined form: two target sets, the gather of frame i in flight while frame i+1 is produced
+    g2 = [BandGather(H, W, torch.float32, "cpu", rank, world) for _ in range(2)]
+    locals2 = [local.clone(), local.clone() * 2.0]             # set 1 holds a different "frame"
+    inflight, finals = [None, None], [None, None]
+    for i in range(4):
+        s = i % 2
+        if inflight[s] is not None:
+            finals[s] = g2[s].finish(inflight[s])
+        inflight[s] = g2[s].start(locals2[s])
+    for s in range(2):
+        finals[s] = g2[s].finish(inflight[s])
     if rank == 0:
+        assert torch.equal(finals[0][:H], final[:H]) and torch.equal(finals[1][:H], final[:H] * 2.0)
         np.save(out_path, final[:H].numpy())
     dist.barrier()
     dist.destroy_process_group()
