@@ -116,6 +116,7 @@ SIGNATURES = {
     "frr_debug_atan2f": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "frr_host_atan2f": (C.c_float, [C.c_float, C.c_float]),
     "frr_debug_scan64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "frr_debug_rcp_check": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "frr_debug_gather_calib": (C.c_int, [C.c_void_p, C.c_uint32]),
     "frr_debug_mvp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _P(C.c_float)]),
 }

@@ -829,6 +829,27 @@ int frr_debug_gather_calib(frr_ctx *c, uint32_t log2_records)
     return FRR_OK;
 }
 
+int frr_debug_rcp_check(frr_ctx *c, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches, uint32_t *first_bad)
+{
+    if (!c || !mismatches || !first_bad) return FRR_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long *d = nullptr;
+    if (hipMalloc((void **)&d, 16) != hipSuccess) return fail(c, FRR_ERR_NOMEM, "hipMalloc");
+    const unsigned long long init[2] = {0ull, 0xFFFFFFFFull};
+    hipError_t e = hipMemcpyAsync(d, init, 16, hipMemcpyHostToDevice, c->stream);
+    unsigned long long out[2] = {0, 0};
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_rcp, dim3(4096), dim3(256), 0, c->stream, lo_bits, hi_bits, d, (uint32_t *)(d + 1));
+        e = hipMemcpyAsync(out, d, 16, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, FRR_ERR_HIP, hipGetErrorString(e));
+    *mismatches = out[0];
+    *first_bad = (uint32_t)out[1];
+    return FRR_OK;
+}
+
 int frr_debug_scan64(frr_ctx *c, const uint32_t *in, uint32_t *out)
 {
     if (!c || !in || !out) return FRR_ERR_INVALID;

@@ -292,7 +292,7 @@ __device__ __forceinline__ Frag frag_eval(float s0x_, float s0y_, float s1x_, fl
     float c = fabsf(s0x * s1y - s0y * s1x);
     float s = a + b + c;                                           // :351
     f.valid = !(s == 0.0f);                                        // :352-354
-    float inv = 1.0f / s;                                          // :356-358
+    float inv = recip_exact(s);                                    // :356-358 (== 1.0f / s, bit for bit)
     f.a = a * inv; f.b = b * inv; f.c = c * inv;
     f.rhw = r0 * f.a + r1 * f.b + r2 * f.c;                        // :360
     return f;

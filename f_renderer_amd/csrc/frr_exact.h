@@ -65,6 +65,23 @@ FRR_HD float zkey_decode(uint32_t k)
     return u2f((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
+// 1.0f / s, correctly rounded, in three instructions for the operands the fragment loop sees.
+// v_rcp_f32 is a 1-ulp estimate y; one Newton step written with exact residuals, y + y*(1 - s*y),
+// lands on the IEEE quotient for every s in [2^-64, 2^64] -- verified EXHAUSTIVELY against the
+// compiler's IEEE division on the device (frr_debug_rcp_check, tests/test_gpu_parity.py); operands
+// outside that range (and NaN/inf/0) take the IEEE division.
+FRR_HD float recip_exact(float s)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t e = (f2u(s) >> 23) & 0x1FFu; // sign | exponent
+    if (e - 63u < 129u) {                       // positive, 2^-64 <= s < 2^65
+        const float y = __builtin_amdgcn_rcpf(s);
+        return __builtin_fmaf(y, __builtin_fmaf(-s, y, 1.0f), y);
+    }
+#endif
+    return 1.0f / s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // atan2f: renderer.rs:208-209 calls f32::atan2, i.e. the platform libm.  This is a port of the
 // fdlibm-derived float algorithm glibc 2.35 ships (sysdeps/ieee754/flt-32/e_atan2f.c, s_atanf.c:

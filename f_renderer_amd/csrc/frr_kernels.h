@@ -664,6 +664,18 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
 namespace frr {
 
 // ---- debug --------------------------------------------------------------------------------
+// recip_exact against the IEEE division over a range of bit patterns: number of differing results, first offender
+__global__ __launch_bounds__(256) void k_debug_rcp(uint32_t lo, uint32_t hi, unsigned long long *bad, uint32_t *first)
+{
+    unsigned long long n = 0;
+    for (unsigned long long b = (unsigned long long)lo + blockIdx.x * 256ull + threadIdx.x; b < (unsigned long long)hi; b += gridDim.x * 256ull) {
+        const float s = u2f((uint32_t)b);
+        const float q = 1.0f / s, r = recip_exact(s);
+        if (f2u(q) != f2u(r) && !(q != q && r != r)) { ++n; atomicMin(first, (uint32_t)b); }
+    }
+    if (n) atomicAdd(bad, n);
+}
+
 // MFMA experiment (north_star: "MFMA used only for the batched 4x4 MVP x vertex-block contraction").
 // clip[4][16 vertices] = MVP[4x4] * P[4x16] with v_mfma_f32_16x16x4_f32: A = MVP in rows 0..3 of a 16x4
 // tile, B = (x,y,z,1) of 16 vertices; lane j < 16 receives vertex j's clip xyzw in its 4 accumulators.

@@ -286,6 +286,12 @@ class Renderer:
         self._check(self._lib.frr_profile_get(self._ctx, kernel.encode(), C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def debug_rcp_check(self, lo_bits, hi_bits):
+        """(mismatches, first offending bit pattern) of recip_exact vs the IEEE division on [lo_bits, hi_bits)."""
+        n, first = C.c_uint64(0), C.c_uint32(0)
+        self._check(self._lib.frr_debug_rcp_check(self._ctx, lo_bits, hi_bits, C.byref(n), C.byref(first)))
+        return int(n.value), int(first.value)
+
     def debug_scan64(self, values):
         v = np.ascontiguousarray(values, np.uint32)
         assert v.size == 64

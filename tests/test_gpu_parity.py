@@ -340,3 +340,16 @@ def test_sweep_kernel_still_exact(oracle, mode, monkeypatch):
     r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
     f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
     _assert_frame_equal(r, f)
+
+
+def test_fast_reciprocal_is_ieee_exact_for_every_float():
+    """recip_exact (v_rcp_f32 + one exact-residual Newton step, IEEE division outside [2^-64, 2^65)) is
+    what the fragment loop uses for `1.0 / s` (renderer.rs:356): all 2^32 bit patterns on the device."""
+    import f_renderer_amd as fr
+    r = fr.Renderer(64, 64)
+    total = 0
+    for lo, hi in ((0, 0x40000000), (0x40000000, 0x80000000), (0x80000000, 0xC0000000), (0xC0000000, 0xFFFFFFFF)):
+        n, first = r.debug_rcp_check(lo, hi)
+        assert n == 0, f"{n} mismatches, first at bit pattern {first:#x}"
+        total += n
+    assert total == 0
