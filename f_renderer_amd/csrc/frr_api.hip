@@ -581,9 +581,13 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + 3071) / 3072, 1), BIN_MAX_G);
         if (c->bin_g > 0) G = (uint32_t)std::min(c->bin_g, BIN_MAX_G);
         if ((rc = ensure(c, c->bin_matrix, c->bin_matrix_cap, (size_t)BIN_MAX_G * ((size_t)c->max_tiles + 1))) != FRR_OK) return rc;
-        const size_t lds = (size_t)ntiles * sizeof(uint32_t);
+        // dynamic LDS: tile counters + as many staged 16-B records as fit (a chunk emits ~1.8 records per triangle)
+        constexpr size_t kLdsBudget = 160 * 1024 - 1024; // the kernel's static LDS is < 1 KB
+        const size_t hist_bytes = (((size_t)ntiles + 3) & ~(size_t)3) * sizeof(uint32_t);
+        const uint32_t stage_cap = (uint32_t)std::min<size_t>((kLdsBudget - hist_bytes) / 16, 9216);
+        const size_t lds = hist_bytes + (size_t)stage_cap * 16;
         if (!c->lds_attr_set) {
-            HIP_TRY(c, hipFuncSetAttribute((const void *)k_bin_seg, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_LDS_MAX_TILES * 4));
+            HIP_TRY(c, hipFuncSetAttribute((const void *)k_bin_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
             c->lds_attr_set = true;
         }
         c->bin_slot ^= 1;
@@ -596,7 +600,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xBFFFFFFFu);
         if ((rc = ensure(c, c->bins2, c->bin2_cap, (size_t)ntiles * S + a.bin_cap)) != FRR_OK) return rc;
         a.bins2 = c->bins2;
-        { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix, a.slot); }
+        { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix, a.slot, stage_cap); }
     } else {
         // fallback for frames with more tiles than fit LDS counters: global atomics
         const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(c->geom_ntris * FRR_MAX_OUT_TRIS, c->setup_cap) + 255) / 256, 2048);

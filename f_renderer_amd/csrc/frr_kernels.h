@@ -564,9 +564,14 @@ constexpr int BIN_WG = 1024;
 constexpr int BIN_MAX_G = 256;
 constexpr uint32_t BIN_LDS_MAX_TILES = 36864; // 144 KiB of u32 counters
 
-__global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg, int slot)
+__global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg, int slot,
+                                                    uint32_t stage_cap)
 {
-    extern __shared__ uint32_t s_hist[]; // [ntiles]
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[]; // [ntiles], then the staging records
+    // the first stage_cap records of the workgroup's region are collected in LDS in their final order and
+    // leave as coalesced full-line stores (a scattered 16-B store is a partial-line write: WRITE_SIZE showed
+    // 2.3x the bytes); what does not fit goes straight to memory
+    uint4 *s_stage = reinterpret_cast<uint4 *>(s_hist + ((ntiles + 3u) & ~3u));
     __shared__ uint32_t s_w[BIN_WG / 64];
     __shared__ uint32_t s_base;
     const uint32_t g = blockIdx.x, G = gridDim.x;
@@ -584,6 +589,14 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int PF = 4; // bboxes of PF rounds are fetched up front: the loop is latency-bound otherwise
+    uint32_t region = 0; // first record of this workgroup's region (known before the scatter walk)
+    auto put = [&](uint32_t pos, const uint4 &ent) { // pos = ~0u: nothing
+        const uint32_t local = pos - region;
+        if (pos != ~0u) {
+            if (local < stage_cap) s_stage[local] = ent;
+            else if (pos < a.bin_cap) a.bins[pos] = ent;
+        }
+    };
     auto walk = [&](auto scatter_tag) {
         constexpr bool SCATTER = decltype(scatter_tag)::value;
         for (uint32_t base0 = lo + wave * 64u; base0 < hi; base0 += PF * BIN_WG) {
@@ -605,17 +618,35 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
                     if (a.world > 1 && ty % a.world != a.rank) return;
                     const int tile = ty * a.tiles_x + tx;
                     if constexpr (SCATTER) {
-                        const uint32_t pos = atomicAdd(&s_hist[tile], 1u);
-                        if (pos < a.bin_cap) a.bins[pos] = ent;
+                        put(atomicAdd(&s_hist[tile], 1u), ent);
                     } else {
                         atomicAdd(&s_hist[tile], 1u);
                     }
                 };
                 const uint4 mine = make_uint4(i, pb[k].z, pb[k].x, pb[k].y);
-                if (nt > 0 && nt <= BIN_COOP)
-                    for (int ty = t.ty0; ty < t.ty1; ++ty)
-                        for (int tx = t.tx0; tx < t.tx1; ++tx) visit(mine, tx, ty);
-                unsigned long long big = __ballot(nt > BIN_COOP);
+                // footprints of at most 2x2 tiles (the common case) as straight-line code: up to four
+                // independent LDS atomics in flight instead of a loop of dependent atomic -> store steps
+                const bool small = nt > 0 && ntx <= 2 && nty <= 2;
+                if (small) {
+                    const bool own0 = a.world <= 1 || t.ty0 % a.world == a.rank;
+                    const bool own1 = nty == 2 && (a.world <= 1 || (t.ty0 + 1) % a.world == a.rank);
+                    const int t00 = t.ty0 * a.tiles_x + t.tx0;
+                    const bool v0 = own0, v1 = own0 && ntx == 2, v2 = own1, v3 = own1 && ntx == 2;
+                    if constexpr (SCATTER) {
+                        uint32_t p0 = ~0u, p1 = ~0u, p2 = ~0u, p3 = ~0u;
+                        if (v0) p0 = atomicAdd(&s_hist[t00], 1u);
+                        if (v1) p1 = atomicAdd(&s_hist[t00 + 1], 1u);
+                        if (v2) p2 = atomicAdd(&s_hist[t00 + a.tiles_x], 1u);
+                        if (v3) p3 = atomicAdd(&s_hist[t00 + a.tiles_x + 1], 1u);
+                        put(p0, mine); put(p1, mine); put(p2, mine); put(p3, mine);
+                    } else {
+                        if (v0) atomicAdd(&s_hist[t00], 1u);
+                        if (v1) atomicAdd(&s_hist[t00 + 1], 1u);
+                        if (v2) atomicAdd(&s_hist[t00 + a.tiles_x], 1u);
+                        if (v3) atomicAdd(&s_hist[t00 + a.tiles_x + 1], 1u);
+                    }
+                }
+                unsigned long long big = __ballot(nt > 0 && !small);
                 while (big) {
                     const int src = __builtin_ctzll(big);
                     big &= big - 1;
@@ -656,7 +687,12 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) row[t] = s_hist[t];
     if (threadIdx.x == 0) row[ntiles] = (uint32_t)min((unsigned long long)base + total, (unsigned long long)a.bin_cap);
     __syncthreads(); // rows are read from LDS above before the cursors start moving
+    region = base;
     walk(std::true_type{});
+    __syncthreads();
+    const uint32_t nstaged = min(total, stage_cap);
+    for (uint32_t j = threadIdx.x; j < nstaged; j += BIN_WG)
+        if (base + j < a.bin_cap) a.bins[base + j] = s_stage[j];
 }
 
 } // namespace frr
