@@ -9,9 +9,10 @@ list) are in HBM before the timed region starts.
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Multi-GPU: one process per GPU; the framebuffer is partitioned by interleaved 32-px tile rows
-(rank r owns rows ty % N == r), geometry is replicated, and the only collective is one RCCL
-gather of the owned bands to rank 0 per frame.  Total work is fixed => "scaling": "strong".
+Multi-GPU: one process per GPU; the framebuffer is partitioned into N contiguous blocks of 32-px tile
+rows (frr_set_partition_layout: blocked), geometry is replicated, and the only collective is one RCCL
+gather of the owned slabs to rank 0 per frame, read straight from the render target and overlapped with
+the next frame.  Total work is fixed => "scaling": "strong".
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -125,7 +126,7 @@ def main():
         r = fr.Renderer(W, H, device=local_rank, stream=stream.cuda_stream)
         # frame targets live in torch tensors (plumbing: device memory + the gather's operands);
         # rows are padded to a whole number of tile rows per rank so owned bands are one strided view
-        from f_renderer_amd.multigpu import BandGather, band_layout
+        from f_renderer_amd.multigpu import BlockGather, band_layout
         _, _, HP = band_layout(H, world)
         # two target sets: frame i renders into set i % 2 while the gather of frame i-1 (other set) is in flight
         nsets = 2 if dist is not None else 1
@@ -133,11 +134,11 @@ def main():
         depth = [torch.zeros((HP, W), dtype=torch.float32, device="cuda") for _ in range(nsets)]
         tri_id = [torch.full((HP, W), -1, dtype=torch.int32, device="cuda") for _ in range(nsets)]
         r.bind_targets(color[0].data_ptr(), depth[0].data_ptr(), tri_id[0].data_ptr())
-        r.set_partition(rank, world)
+        r.set_partition(rank, world, blocked=True)   # contiguous slabs: the gather needs no staging copies
         dev_in = torch.from_numpy(tris).to("cuda")  # resident in HBM before timing
         mesh = r.bind_mesh_device(dev_in.data_ptr(), ntris, fr.VS_CLIP, keepalive=dev_in)
         gh = H // max(1, args.gather_rows_div) if world == 1 else H
-        gathers = [BandGather(gh, W, torch.float32, "cuda", rank, world) for _ in range(nsets)] if dist is not None else None
+        gathers = [BlockGather(gh, W, torch.float32, "cuda", rank, world) for _ in range(nsets)] if dist is not None else None
         ghp = band_layout(gh, world)[2]
         inflight = [None] * nsets
         final = None
@@ -230,7 +231,7 @@ def main():
             "config": {"workload": args.workload, "width": W, "height": H, "triangles": ntris,
                        "setup_triangles": stats["tris_setup"], "covered_fragments": frag_covered,
                        "shader": "VS_CLIP/PS_DEPTH (depth-only)", "tile": "32x32",
-                       "partition": f"tile rows interleaved over {world} rank(s)" + (", RCCL gather to rank 0" if world > 1 else "")},
+                       "partition": f"tile rows in {world} contiguous block(s)" + (", RCCL gather to rank 0" if world > 1 else "")},
         }
         if image_ok is not None:
             line["gathered_image_finite"] = image_ok

@@ -87,6 +87,7 @@ SIGNATURES = {
     "frr_destroy": (None, [C.c_void_p]),
     "frr_last_error": (C.c_char_p, [C.c_void_p]),
     "frr_set_partition": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "frr_set_partition_layout": (C.c_int, [C.c_void_p, C.c_int]),
     "frr_set_count_fragments": (C.c_int, [C.c_void_p, C.c_int]),
     "frr_bind_targets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frr_target_ptrs": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_void_p)]),

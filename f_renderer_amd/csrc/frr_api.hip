@@ -53,10 +53,12 @@ struct frr_ctx {
     // frr_clear is deferred: the first full-window draw of the span kernel performs it inside the tile kernel
     // (keys start from the clear depth, every pixel of the tile is written); anything else that looks at the
     // targets or the counters first settles it with k_clear.  FRR_CLEAR=eager restores the immediate clear.
+    bool part_blocked = false;     // frr_set_partition_layout: contiguous blocks of tile rows instead of interleaved rows
     bool clear_eager = false;
     bool clear_pending = false;    // targets not cleared yet
     bool counters_pending = false; // frame counters not reset yet (the next draw's bookkeeping thread does it)
     bool unowned_debt = false;     // partitioned ctx: the tile rows of other ranks missed a fused clear
+    int debt_rpr = 0;              //   (RasterArgs::rpr of the draw that left the debt)
     uint32_t clear_rgba = 0; float clear_depth = 0.0f;
     int bin_slot = 0;          // Counters::seg_total / ent_cursor slot of the latest draw (alternates)
     bool bin_atomics = false;  // FRR_BIN=atomics: force the global-atomic binning fallback (tests)
@@ -340,6 +342,13 @@ int frr_set_partition(frr_ctx *c, int rank, int world)
     c->rank = rank; c->world = world;
     return FRR_OK;
 }
+int frr_set_partition_layout(frr_ctx *c, int blocked)
+{
+    if (!c) return FRR_ERR_INVALID;
+    { int rc = settle(c); if (rc != FRR_OK) return rc; }
+    c->part_blocked = blocked != 0;
+    return FRR_OK;
+}
 int frr_set_count_fragments(frr_ctx *c, int enable)
 {
     if (!c) return FRR_ERR_INVALID;
@@ -458,7 +467,7 @@ static int settle(frr_ctx *c)
         c->clear_pending = c->counters_pending = c->unowned_debt = false;
     } else if (c->unowned_debt) {
         hipLaunchKernelGGL(k_clear_unowned_rows, dim3(c->H), dim3(256), 0, c->stream, (uint32_t *)c->color, (uint32_t *)c->depth,
-                           c->tri_id, c->W, c->H, c->rank, c->world, c->clear_rgba, c->clear_depth);
+                           c->tri_id, c->W, c->H, c->rank, c->world, c->debt_rpr, c->clear_rgba, c->clear_depth);
         HIP_TRY(c, hipGetLastError());
         c->unowned_debt = false;
     }
@@ -511,6 +520,11 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     g.group_sums = c->group_sums + (size_t)c->geom_slot * 128 * GROUP_PAD;
     g.group_zero = c->group_sums + (size_t)(c->geom_slot ^ 1) * 128 * GROUP_PAD;
     g.part_rank = c->rank; g.part_world = filter ? c->world : 1; g.part_y0 = fy0; g.part_y1 = fy1;
+    g.part_rpr = 0;
+    if (filter && c->part_blocked) {
+        const int tiles_y = (int)(((int64_t)fy1 - fy0 + TILE - 1) / TILE);
+        g.part_rpr = std::max(1, (tiles_y + c->world - 1) / c->world);
+    }
     g.block_sums = c->block_sums; g.clip_list = c->clip_list; g.cslot = c->geom_slot;
     g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;
     if (nt == 0) {
@@ -562,6 +576,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     a.cstride = (int)c->W; a.dstride = x1;
     a.tiles_x = (int)((ww + TILE - 1) / TILE); a.tiles_y = (int)((wh + TILE - 1) / TILE);
     a.rank = c->rank; a.world = c->world;
+    a.rpr = (c->part_blocked && c->world > 1) ? std::max(1, (a.tiles_y + c->world - 1) / c->world) : 0;
     a.recs = c->recs; a.vary = c->vary; a.pbox = c->pbox;
     a.tile_counts = c->tile_counts; a.tile_offsets = c->tile_offsets; a.tile_cursor = c->tile_cursor;
     const uint32_t ntiles = (uint32_t)a.tiles_x * a.tiles_y;
@@ -608,7 +623,8 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         { ProfScope p(c, KID_TILE_SCAN); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, a, ntiles); }
         { ProfScope p(c, KID_BIN_FILL); hipLaunchKernelGGL(k_bin<true>, dim3(bin_grid), dim3(256), 0, c->stream, a); }
     }
-    const int owned_rows = a.tiles_y > a.rank ? (a.tiles_y - a.rank + a.world - 1) / a.world : 0;
+    const int owned_rows = a.rpr > 0 ? std::max(0, std::min(a.tiles_y, (a.rank + 1) * a.rpr) - a.rank * a.rpr)
+                                     : (a.tiles_y > a.rank ? (a.tiles_y - a.rank + a.world - 1) / a.world : 0);
     const uint32_t grid = (uint32_t)a.tiles_x * owned_rows;
     if (grid) {
         switch (ps_id) {
@@ -625,6 +641,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         // the tile rows of other ranks missed this clear: owed to the ctx's own targets (frr_readback shows the
         // whole image); caller-bound targets of a partitioned ctx only ever have their owned rows defined
         c->unowned_debt = c->world > 1 && c->color == c->own_color && c->depth == c->own_depth && c->tri_id == c->own_tri_id;
+        c->debt_rpr = a.rpr;
     }
     return FRR_OK;
 }

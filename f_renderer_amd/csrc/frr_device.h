@@ -69,6 +69,7 @@ struct GeomArgs {
     uint32_t *group_zero;   // ... and the previous draw's slot, zeroed by this draw's count kernel
     int32_t part_rank, part_world; // tile-row ownership filter (world == 1: none); only set by frr_draw,
     int32_t part_y0, part_y1;      // which knows the raster window's height range
+    int32_t part_rpr;              // > 0: blocked partition (RasterArgs::rpr)
     uint32_t *block_sums;   // [nblocks] setup triangles per count block; exclusive-scanned in place by k_scan_blocks (MODE 0)
     uint2 *clip_list;       // [<= ntris] clipped triangles of this draw: (input index, offset within its block | fan size << 16)
     int32_t cslot;          // Counters::clip_n slot of this draw
@@ -83,7 +84,8 @@ struct RasterArgs {
     int32_t win_w, win_h;             // x1-x0, y1-y0
     int32_t cstride, dstride;         // colour row stride (fb.width), depth row stride (= x1, :362)
     int32_t tiles_x, tiles_y;
-    int32_t rank, world;              // tile-row ownership (ty % world == rank)
+    int32_t rank, world;              // tile-row ownership: ty % world == rank (interleaved), or ...
+    int32_t rpr;                      // ... rpr > 0: blocked, rank owns tile rows [rank*rpr, (rank+1)*rpr)
     const RasterRec *recs;
     const float *vary;
     const uint4 *pbox;                // see GeomArgs::pbox
@@ -107,6 +109,12 @@ struct RasterArgs {
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// which rank rasterizes tile row ty (window-local): interleaved (rpr == 0) or blocks of rpr rows
+__device__ __forceinline__ bool owns_tile_row(int ty, int rank, int world, int rpr)
+{
+    return world <= 1 || (rpr > 0 ? ty / rpr == rank : ty % world == rank);
+}
 
 // what frr_clear does to the counters (by k_clear, or deferred to the next draw's bookkeeping thread)
 __device__ __forceinline__ void reset_frame_counters(Counters *cnt)

@@ -28,10 +28,10 @@ __global__ __launch_bounds__(256) void k_clear(uint4 *__restrict__ color, uint4 
 // brought up to date only when somebody looks: frr_readback, frr_target_ptrs)
 __global__ __launch_bounds__(256) void k_clear_unowned_rows(uint32_t *__restrict__ color, uint32_t *__restrict__ depth,
                                                             uint32_t *__restrict__ ids, uint32_t W, uint32_t H, int rank,
-                                                            int world, uint32_t rgba, float d)
+                                                            int world, int rpr, uint32_t rgba, float d)
 {
     const uint32_t y = blockIdx.x;
-    if (y >= H || (int)((y / TILE) % (uint32_t)world) == rank) return;
+    if (y >= H || owns_tile_row((int)(y / TILE), rank, world, rpr)) return;
     for (uint32_t x = threadIdx.x; x < W; x += 256u) {
         const size_t i = (size_t)y * W + x;
         color[i] = rgba; depth[i] = f2u(d); ids[i] = ~0u;
@@ -324,8 +324,12 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
         owned = false;
         if (maxy > miny) {
             const int ty0 = (miny - g.part_y0) / TILE, ty1 = (maxy - 1 - g.part_y0) / TILE;
-            const int first = ty0 + ((g.part_rank - ty0 % g.part_world) + g.part_world) % g.part_world;
-            owned = first <= ty1;
+            if (g.part_rpr > 0) {
+                owned = ty0 < (g.part_rank + 1) * g.part_rpr && ty1 >= g.part_rank * g.part_rpr;
+            } else {
+                const int first = ty0 + ((g.part_rank - ty0 % g.part_world) + g.part_world) % g.part_world;
+                owned = first <= ty1;
+            }
         }
         if (!owned) g.pbox[off] = make_uint4(0u, 0u, 0u, 0u);
     }
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256) void k_bin(RasterArgs a)
         const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
         const int nt = ntx * nty;
         auto visit = [&](const uint4 &ent, int tx, int ty) {
-            if (a.world > 1 && ty % a.world != a.rank) return;
+            if (!owns_tile_row(ty, a.rank, a.world, a.rpr)) return;
             const int tile = ty * a.tiles_x + tx;
             if constexpr (FILL) {
                 uint32_t pos = a.tile_offsets[tile] + atomicAdd(&a.tile_cursor[tile], 1u);
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
                 const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
                 const int nt = ntx * nty;
                 auto visit = [&](const uint4 &ent, int tx, int ty) {
-                    if (a.world > 1 && ty % a.world != a.rank) return;
+                    if (!owns_tile_row(ty, a.rank, a.world, a.rpr)) return;
                     const int tile = ty * a.tiles_x + tx;
                     if constexpr (SCATTER) {
                         put(atomicAdd(&s_hist[tile], 1u), ent);
@@ -628,8 +632,8 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
                 // independent LDS atomics in flight instead of a loop of dependent atomic -> store steps
                 const bool small = nt > 0 && ntx <= 2 && nty <= 2;
                 if (small) {
-                    const bool own0 = a.world <= 1 || t.ty0 % a.world == a.rank;
-                    const bool own1 = nty == 2 && (a.world <= 1 || (t.ty0 + 1) % a.world == a.rank);
+                    const bool own0 = owns_tile_row(t.ty0, a.rank, a.world, a.rpr);
+                    const bool own1 = nty == 2 && owns_tile_row(t.ty0 + 1, a.rank, a.world, a.rpr);
                     const int t00 = t.ty0 * a.tiles_x + t.tx0;
                     const bool v0 = own0, v1 = own0 && ntx == 2, v2 = own1, v3 = own1 && ntx == 2;
                     if constexpr (SCATTER) {

@@ -39,7 +39,7 @@ __device__ __forceinline__ TileCtx tile_ctx(const RasterArgs &a)
     TileCtx c;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tx = bid % a.tiles_x;
-    const int ty = a.rank + (bid / a.tiles_x) * a.world;
+    const int ty = a.rpr > 0 ? a.rank * a.rpr + bid / a.tiles_x : a.rank + (bid / a.tiles_x) * a.world;
     c.tile = ty * a.tiles_x + tx;
     c.lx0 = tx * TILE; c.ly0 = ty * TILE;
     c.tw = min(TILE, a.win_w - c.lx0); c.th = min(TILE, a.win_h - c.ly0);

@@ -114,7 +114,11 @@ public:
     void free_mesh(Mesh &m) { if (m.id >= 0) { check(frr_mesh_free(ctx_, m.id)); m.id = -1; } }
     void set_texture(int slot, const FrameBuffer &fb) { check(frr_texture_upload(ctx_, slot, fb.get_data().data(), fb.width(), fb.height())); }
     void set_uniforms() { check(frr_set_uniforms(ctx_, &uniforms)); }
-    void set_partition(int rank, int world) { check(frr_set_partition(ctx_, rank, world)); }
+    void set_partition(int rank, int world, bool blocked = false)
+    {
+        check(frr_set_partition(ctx_, rank, world));
+        check(frr_set_partition_layout(ctx_, blocked ? 1 : 0));
+    }
 
     // frame_buffer.fill(color); depth_buffer.fill(depth)   (phong.rs:316-317)
     void clear(const std::array<uint8_t, 4> &color = {30, 30, 30, 255}, float depth = 0.0f) { check(frr_clear(ctx_, color.data(), depth)); }

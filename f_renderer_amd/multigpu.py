@@ -1,5 +1,10 @@
 """Screen-tile partition across ranks and the final-image gather (one process per GPU).
 
+Two ownership layouts (`frr_set_partition_layout`): interleaved tile rows (BandGather below: the owned
+bands are staged into one contiguous buffer and interleaved back on the destination) and blocked tile
+rows (BlockGather: a rank's part of the row-major image is one contiguous slab, so the gather reads the
+render target and writes the final image directly -- no staging copies; bench.py uses this one).
+
 The path shards by screen tiles: rank r owns the 32-pixel tile rows ty with ty % world == r
 (`frr_set_partition`, include/frr.h); geometry is replicated; there is no data-path collective
 during a frame.  The only exchange is ONE gather of the owned bands to rank 0 for the final image
@@ -74,3 +79,37 @@ class BandGather:
             v.copy_(self.gbuf.transpose(0, 1))                             # interleave the bands back
             return self.final
         return None
+
+
+def block_rows(height, rank, world):
+    """Pixel rows [y0, y1) of the padded image that `rank` owns in the blocked layout."""
+    _, rows_per_rank, _ = band_layout(height, world)
+    return rank * rows_per_rank * TILE, (rank + 1) * rows_per_rank * TILE
+
+
+class BlockGather:
+    """Blocked layout: rank r owns the contiguous pixel rows block_rows(height, r, world) of the padded
+    image, so its slab is gathered straight from the render target into the final image on `dst`."""
+
+    def __init__(self, height, width, dtype, device, rank, world, dst=0, trailing=()):
+        self.rank, self.world, self.dst = rank, world, dst
+        _, self.rows_per_rank, self.padded_height = band_layout(height, world)
+        self.slab = self.rows_per_rank * TILE
+        if rank == dst:
+            self.final = torch.zeros((self.padded_height, width, *trailing), dtype=dtype, device=device)
+            self.gathered = list(self.final.view(world, self.slab, width, *trailing).unbind(0))  # contiguous views
+        else:
+            self.final, self.gathered = None, None
+
+    def start(self, local_image, group=None):
+        """Launches the gather of this rank's slab of `local_image` ([HP, W, ...]) without waiting for it."""
+        import torch.distributed as dist
+        y0, y1 = self.rank * self.slab, (self.rank + 1) * self.slab
+        return dist.gather(local_image[y0:y1], self.gathered, dst=self.dst, group=group, async_op=True)
+
+    def finish(self, handle):
+        handle.wait()
+        return self.final
+
+    def __call__(self, local_image, group=None):
+        return self.finish(self.start(local_image, group))

@@ -192,8 +192,11 @@ class Renderer:
             u.texture_slot = int(texture_slot)
         self._check(self._lib.frr_set_uniforms(self._ctx, C.byref(u)))
 
-    def set_partition(self, rank, world):
+    def set_partition(self, rank, world, blocked=False):
+        """Tile-row ownership of a multi-GPU rank: interleaved rows (ty % world == rank) or, blocked=True,
+        the contiguous rows [rank*k, (rank+1)*k), k = ceil(tile_rows / world)."""
         self._check(self._lib.frr_set_partition(self._ctx, rank, world))
+        self._check(self._lib.frr_set_partition_layout(self._ctx, 1 if blocked else 0))
 
     def set_count_fragments(self, enable):
         self._check(self._lib.frr_set_count_fragments(self._ctx, 1 if enable else 0))

@@ -106,6 +106,11 @@ int frr_abi_version(void);
 /* Screen-tile partition for multi-GPU runs: this ctx rasterizes only tile rows ty with
  * ty % world == rank (geometry is replicated).  Default (0,1) = everything. */
 int frr_set_partition(frr_ctx *ctx, int rank, int world);
+/* Which tile rows a rank owns: 0 (default) = interleaved, ty % world == rank -- balances scenes whose
+ * load varies down the screen; 1 = blocked, rank owns the contiguous rows [rank*k, (rank+1)*k) with
+ * k = ceil(tile_rows / world) -- its part of a row-major image is then ONE contiguous slab, so the
+ * final-image gather needs no staging copies (bench.py uses this). */
+int frr_set_partition_layout(frr_ctx *ctx, int blocked);
 /* frr_stats.frag_covered is exact while counting is enabled (default).  Disabling it lets the tile
  * kernel drop whole triangles by hierarchical early-z before their coverage is known (images are
  * identical either way; only the statistic stops being maintained). */

@@ -52,7 +52,8 @@ def test_headline_early_z_and_repeat_are_identical(headline):
     r.set_count_fragments(True)
 
 
-def test_headline_partition_of_8_stitches_and_counts_add_up(headline):
+@pytest.mark.parametrize("blocked", [False, True])
+def test_headline_partition_of_8_stitches_and_counts_add_up(headline, blocked):
     import f_renderer_amd as fr
     G = 8
     rows = np.arange(H) // 32
@@ -61,13 +62,14 @@ def test_headline_partition_of_8_stitches_and_counts_add_up(headline):
     covered = 0
     for rank in range(G):
         r = fr.Renderer(W, H)
-        r.set_partition(rank, G)
+        r.set_partition(rank, G, blocked=blocked)
         r.set_count_fragments(True)
         r.clear()
         r.draw(r.upload_mesh(headline["tris"], fr.VS_CLIP), fr.PS_DEPTH)
         _, d, t = r.readback()
         covered += r.stats()["frag_covered"]
-        own = np.repeat((rows % G) == rank, W)
+        k = -(-((H + 31) // 32) // G)
+        own = np.repeat((rows // k) == rank if blocked else (rows % G) == rank, W)
         acc_t[own] = t[own]
         acc_d[own] = d[own]
         r.close()

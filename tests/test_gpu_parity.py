@@ -244,9 +244,11 @@ def test_window_errors(oracle):
     r.sync()
 
 
-def test_tile_partition_stitch(oracle):
-    """Screen-tile partition (multi-GPU scheme): rank r of G renders tile rows ty % G == r; the
-    union of the G partial images must be byte-identical to the 1-GPU image."""
+@pytest.mark.parametrize("blocked", [False, True])
+def test_tile_partition_stitch(oracle, blocked):
+    """Screen-tile partition (multi-GPU scheme): rank r of G renders tile rows ty % G == r (interleaved) or
+    the contiguous rows [r*k, (r+1)*k), k = ceil(rows/G) (blocked); the union of the G partial images must
+    be byte-identical to the 1-GPU image."""
     import f_renderer_amd as fr
     from f_renderer_amd import scenes
     W, H, G = 300, 200, 3
@@ -260,11 +262,12 @@ def test_tile_partition_stitch(oracle):
     rows = np.arange(H) // 32
     for rank in range(G):
         r = fr.Renderer(W, H)
-        r.set_partition(rank, G)
+        r.set_partition(rank, G, blocked=blocked)
         r.clear()
         r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
         _, d, t = r.readback()
-        own = np.repeat((rows % G) == rank, W)
+        k = -(-((H + 31) // 32) // G)
+        own = np.repeat((rows // k) == rank if blocked else (rows % G) == rank, W)
         assert (t[~own] == 0xFFFFFFFF).all()
         acc_d[own] = d[own]
         acc_t[own] = t[own]

@@ -43,8 +43,18 @@ def _worker(rank, world, port, H, W, full_np, out_path):
         inflight[s] = g2[s].start(locals2[s])
     for s in range(2):
         finals[s] = g2[s].finish(inflight[s])
+    # blocked layout (frr_set_partition_layout(1)): contiguous slabs, gathered straight from the image
+    from f_renderer_amd.multigpu import BlockGather, block_rows
+    y0, y1 = block_rows(H, rank, world)
+    local_b = torch.zeros((HP, W), dtype=torch.float32)
+    y1c = min(y1, H)
+    if y0 < H:
+        local_b[y0:y1c] = full[y0:y1c]
+    bg = BlockGather(H, W, torch.float32, "cpu", rank, world)
+    final_b = bg.finish(bg.start(local_b))
     if rank == 0:
         assert torch.equal(finals[0][:H], final[:H]) and torch.equal(finals[1][:H], final[:H] * 2.0)
+        assert torch.equal(final_b[:H], final[:H])
         np.save(out_path, final[:H].numpy())
     dist.barrier()
     dist.destroy_process_group()
