@@ -593,7 +593,8 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     a.seg = nullptr; a.nseg = 0; a.slot = 0;
     if (ntiles <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep) {
         // segmented LDS multi-split (one launch, no per-entry global atomics): G chunk workgroups, ~3K triangles each
-        uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + 3071) / 3072, 1), BIN_MAX_G);
+        // (small meshes: one triangle per thread, so that the launch is not three workgroups doing all the work)
+        uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + BIN_WG - 1) / BIN_WG, 1), BIN_MAX_G);
         if (c->bin_g > 0) G = (uint32_t)std::min(c->bin_g, BIN_MAX_G);
         if ((rc = ensure(c, c->bin_matrix, c->bin_matrix_cap, (size_t)BIN_MAX_G * ((size_t)c->max_tiles + 1))) != FRR_OK) return rc;
         // dynamic LDS: tile counters + as many staged 16-B records as fit (a chunk emits ~1.8 records per triangle)

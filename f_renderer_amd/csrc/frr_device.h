@@ -132,7 +132,7 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 }
 __device__ __forceinline__ void normalize3(float &x, float &y, float &z)
 {
-    float r = 1.0f / sqrtf(dot3(x, y, z, x, y, z)); // Vec3::normalize = self * length_recip()
+    float r = recip_exact(sqrtf(dot3(x, y, z, x, y, z))); // Vec3::normalize = self * length_recip(); == 1.0f / sqrt, bit for bit
     x = x * r; y = y * r; z = z * r;
 }
 __device__ __forceinline__ void mat4_mul_vec4(const float *m, float x, float y, float z, float w, float o[4])
@@ -308,7 +308,9 @@ __device__ __forceinline__ Frag frag_eval(float s0x_, float s0y_, float s1x_, fl
 
 // ---- pixel shader table (contract renderer.rs:283,380) ----------------------------------
 // FrameBuffer::sample_2d renderer.rs:516-538 (+ get_pixel :505-514, u8_array_to_vec4 :16-24)
-__device__ __forceinline__ void sample_2d(const DevUniforms &u, float uu, float vv, float out[4])
+// u8lut: optional 256-entry table of (float)i / 255.0f (the tile kernel keeps one in LDS: the 16 IEEE
+// divisions of a bilinear sample become 16 table reads of the very same quotients)
+__device__ __forceinline__ void sample_2d(const DevUniforms &u, float uu, float vv, float out[4], const float *u8lut = nullptr)
 {
     float x = uu * (float)u.tex_w;
     float y = vv * (float)u.tex_h;
@@ -327,16 +329,18 @@ __device__ __forceinline__ void sample_2d(const DevUniforms &u, float uu, float 
     const uint8_t *p21 = reinterpret_cast<const uint8_t *>(&q21), *p22 = reinterpret_cast<const uint8_t *>(&q22);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float c11 = ((float)p11[k] / 255.0f) * oma * omb;
-        float c12 = ((float)p12[k] / 255.0f) * oma * b;
-        float c21 = ((float)p21[k] / 255.0f) * a * omb;
-        float c22 = ((float)p22[k] / 255.0f) * a * b;
+        const float t11 = u8lut ? u8lut[p11[k]] : (float)p11[k] / 255.0f, t12 = u8lut ? u8lut[p12[k]] : (float)p12[k] / 255.0f;
+        const float t21 = u8lut ? u8lut[p21[k]] : (float)p21[k] / 255.0f, t22 = u8lut ? u8lut[p22[k]] : (float)p22[k] / 255.0f;
+        float c11 = t11 * oma * omb;
+        float c12 = t12 * oma * b;
+        float c21 = t21 * a * omb;
+        float c22 = t22 * a * b;
         out[k] = c11 + c12 + c21 + c22;
     }
 }
 
 template <int PS>
-__device__ __forceinline__ void run_ps(const DevUniforms &u, const float *ctx, float out[4])
+__device__ __forceinline__ void run_ps(const DevUniforms &u, const float *ctx, float out[4], const float *u8lut = nullptr)
 {
     if constexpr (PS == FRR_PS_FLAT) {
         out[0] = u.flat_color[0]; out[1] = u.flat_color[1]; out[2] = u.flat_color[2]; out[3] = u.flat_color[3];
@@ -367,7 +371,7 @@ __device__ __forceinline__ void run_ps(const DevUniforms &u, const float *ctx, f
         }
         s = s * s; s = s * s; s = s * s; s = s * s; s = s * s;                            // powi(32)
         float tex[4];
-        sample_2d(u, ctx[0], ctx[1], tex);                                                // :146-151
+        sample_2d(u, ctx[0], ctx[1], tex, u8lut);                                         // :146-151
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float diffuse = diff * u.light_color[k];                                      // :139

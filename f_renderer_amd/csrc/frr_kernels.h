@@ -650,7 +650,10 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
                         if (v3) atomicAdd(&s_hist[t00 + a.tiles_x + 1], 1u);
                     }
                 }
-                unsigned long long big = __ballot(nt > 0 && !small);
+                if (!small && nt > 0 && nt <= BIN_COOP) // 3x1, 1x3, 3x2, ...: per lane
+                    for (int ty = t.ty0; ty < t.ty1; ++ty)
+                        for (int tx = t.tx0; tx < t.tx1; ++tx) visit(mine, tx, ty);
+                unsigned long long big = __ballot(nt > BIN_COOP);
                 while (big) {
                     const int src = __builtin_ctzll(big);
                     big &= big - 1;

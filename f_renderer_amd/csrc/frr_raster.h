@@ -84,7 +84,7 @@ __device__ __forceinline__ void tile_fill_clear(const RasterArgs &a, const TileC
 // resolve: the owner of each pixel is re-evaluated with the same arithmetic and written out
 template <int K, int PS>
 __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUniforms &u, const TileCtx &c,
-                                             const unsigned long long *s_key)
+                                             const unsigned long long *s_key, const float *u8lut = nullptr)
 {
     const uint32_t tri_base = a.cnt->tri_base;
     for (int i = threadIdx.x; i < TILE_PX; i += (int)blockDim.x) {
@@ -118,7 +118,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
         a.depth[di] = f.rhw;                                                    // :366
         a.tri_id[di] = tri_base + t;
         if constexpr (PS != FRR_PS_DEPTH) {
-            const float w = 1.0f / (f.rhw != 0.0f ? f.rhw : 1.0f);              // :368
+            const float w = recip_exact(f.rhw != 0.0f ? f.rhw : 1.0f);          // :368 (== 1.0f / x, bit for bit)
             const float c0 = r0 * f.a * w, c1 = r1 * f.b * w, c2 = r2 * f.c * w; // :370-372
             float in[K > 0 ? K : 1];
             if constexpr (K > 0) {
@@ -127,7 +127,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
                 for (int k = 0; k < K; ++k) in[k] = v[k] * c0 + v[K + k] * c1 + v[2 * K + k] * c2; // :374-378
             }
             float col[4];
-            run_ps<PS>(u, in, col);                                             // :380
+            run_ps<PS>(u, in, col, u8lut);                                      // :380
             const uint32_t q = quantize_u8(col[0]) | (quantize_u8(col[1]) << 8) | (quantize_u8(col[2]) << 16) |
                                (quantize_u8(col[3]) << 24);                     // :7-14
             reinterpret_cast<uint32_t *>(a.color)[(size_t)(c.ly0 + y) * a.cstride + (c.lx0 + x)] = q; // :381,:496-503
@@ -341,6 +341,9 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
     __shared__ uint32_t s_segsrc[BIN_MAX_G];          //                     where segment g starts in a.bins
     __shared__ uint32_t s_w4[4];
     __shared__ uint32_t s_ebase;
+    constexpr bool TEXTURED = PS == FRR_PS_PHONG || PS == FRR_PS_BLINN;
+    __shared__ float s_u8[TEXTURED ? 256 : 1];       // (float)i / 255.0f for the texture taps of the resolve
+    if (TEXTURED) for (int i = threadIdx.x; i < 256; i += NW * 64) s_u8[i] = (float)i / 255.0f; // ordered by the barriers below
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     TileCtx c = tile_ctx(a);
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
 #endif
     if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
     __syncthreads();
-    tile_resolve<K, PS>(a, u, c, s_key);
+    tile_resolve<K, PS>(a, u, c, s_key, TEXTURED ? s_u8 : nullptr);
 }
 
 // debug: the DPP scan against a serial sum (tests)
