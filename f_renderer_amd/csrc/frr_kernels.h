@@ -650,10 +650,28 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
                         if (v3) atomicAdd(&s_hist[t00 + a.tiles_x + 1], 1u);
                     }
                 }
-                if (!small && nt > 0 && nt <= BIN_COOP) // 3x1, 1x3, 3x2, ...: per lane
-                    for (int ty = t.ty0; ty < t.ty1; ++ty)
-                        for (int tx = t.tx0; tx < t.tx1; ++tx) visit(mine, tx, ty);
-                unsigned long long big = __ballot(nt > BIN_COOP);
+                // footprints up to 3x3 tiles, same idea (nine predicated positions); skipped by waves without any
+                const bool mid = nt > 0 && !small && ntx <= 3 && nty <= 3;
+                if (__ballot(mid)) {
+                    uint32_t pos[9];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const bool own = mid && dy < nty && owns_tile_row(t.ty0 + dy, a.rank, a.world, a.rpr);
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const bool v = own && dx < ntx;
+                            const int tile = (t.ty0 + dy) * a.tiles_x + t.tx0 + dx;
+                            pos[dy * 3 + dx] = ~0u;
+                            if constexpr (SCATTER) { if (v) pos[dy * 3 + dx] = atomicAdd(&s_hist[tile], 1u); }
+                            else { if (v) atomicAdd(&s_hist[tile], 1u); }
+                        }
+                    }
+                    if constexpr (SCATTER) {
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) put(pos[q], mine);
+                    }
+                }
+                unsigned long long big = __ballot(nt > 0 && !small && !mid);
                 while (big) {
                     const int src = __builtin_ctzll(big);
                     big &= big - 1;
