@@ -288,6 +288,7 @@ __device__ __forceinline__ void edge_bound(int Er, int A, int thr, int &lo, int 
 // late, or written by another wave a moment ago, is still a valid lower bound: no synchronisation.
 // Layout of the array hz[HZ_SIZE]: [HZ_SEG + row*4 + seg] 8-pixel row segments, [HZ_BLK + by*4 + bx]
 // 8x8 blocks, [HZ_QUAD + qy*2 + qx] 16x16 quads, [HZ_C4 + row*8 + cell] 4-pixel cells of a row.
+constexpr int DIRECT_MAX = 256;  // records of a tile that are culled straight from registers (k_raster_span)
 constexpr int HZ_SEG = 0, HZ_BLK = 128, HZ_QUAD = 144, HZ_C4 = 148, HZ_SIZE = 404;
 __device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uint32_t *hz, int lane)
 {
@@ -402,8 +403,18 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
     // output (the z resolution is order independent); it only makes the hierarchical early-z below
     // reject more.
     uint4 *__restrict__ ents = a.bins2;
-    {
-        const uint32_t nent = c.end - c.beg;
+    // A tile with few records (<= DIRECT_MAX, one per thread) skips the copy altogether: thread (w, lane)
+    // keeps record lane*NW + w in registers and the wave culls its 64 in one step -- no bucket sort, no
+    // bins2 round trip, two barriers less on the chain of a lightly loaded tile.
+    const uint32_t nent = c.end - c.beg;
+    const bool direct = nent <= (uint32_t)DIRECT_MAX;
+    uint4 dent = make_uint4(0, 0, 0, 0);
+    bool dvalid = false;
+    if (direct) {
+        const uint32_t e = (uint32_t)lane * NW + (uint32_t)w;
+        dvalid = e < nent;
+        if (dvalid) dent = source(e);
+    } else {
         const bool sorted = !COUNT && nent > 2u * B;
         auto bucket_of = [&](const uint4 &e) { return sorted ? 63u - ((e.y >> 21) & 63u) : 0u; };
         uint4 ce[4];
@@ -449,14 +460,19 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
         // ---- phase 1a: lane = bin entry, 64 per step.  bbox-in-tile + whole-triangle early-z on the
         // 16-byte cull records only; survivors are queued, nothing else is touched for the rest. ----
         if (!input_done && aq_n == 0) { // survivors are processed before more entries are culled (fresh z minima)
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&s_next, 1u);
-            b = __builtin_amdgcn_readfirstlane(b);
-            const uint32_t e0 = c.beg + b * (uint32_t)SPAN_CULL;
-            if (e0 >= c.end) {
-                input_done = true;
+            uint32_t e0 = 0;
+            bool have = true;
+            if (direct) {
+                input_done = true; // this wave's records are in `dent`: one step
             } else {
-                const int nb64 = (int)min((uint32_t)SPAN_CULL, c.end - e0);
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(&s_next, 1u);
+                b = __builtin_amdgcn_readfirstlane(b);
+                e0 = c.beg + b * (uint32_t)SPAN_CULL;
+                have = e0 < c.end;
+                if (!have) input_done = true;
+            }
+            if (have) {
                 // the minima are rebuilt only if some wave has resolved fragments since the last rebuild
                 // (a stale minimum is a lower one: still conservative)
                 if (__builtin_amdgcn_readfirstlane(s_dirty) != 0u) {
@@ -467,8 +483,8 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
 #endif
                 }
                 wave_lds_fence();
-                const bool valid = lane < nb64;
-                const uint4 en = valid ? ents[e0 + lane] : make_uint4(0, 0, 0, 0);
+                const bool valid = direct ? dvalid : lane < (int)min((uint32_t)SPAN_CULL, c.end - e0);
+                const uint4 en = direct ? dent : (valid ? ents[e0 + lane] : make_uint4(0, 0, 0, 0));
                 const int mnx = (int)(short)(en.z & 0xFFFFu), mny = (int)(short)(en.z >> 16);
                 const int mxx = (int)(short)(en.w & 0xFFFFu), mxy = (int)(short)(en.w >> 16);
                 const int bx0 = max(clampi(mnx, a.x0, a.x1), c.ax0), bx1 = min(clampi(mxx, a.x0, a.x1), c.ax0 + c.tw);
