@@ -288,7 +288,9 @@ __device__ __forceinline__ void edge_bound(int Er, int A, int thr, int &lo, int 
 // late, or written by another wave a moment ago, is still a valid lower bound: no synchronisation.
 // Layout of the array hz[HZ_SIZE]: [HZ_SEG + row*4 + seg] 8-pixel row segments, [HZ_BLK + by*4 + bx]
 // 8x8 blocks, [HZ_QUAD + qy*2 + qx] 16x16 quads, [HZ_C4 + row*8 + cell] 4-pixel cells of a row.
-constexpr int DIRECT_MAX = 256;  // records of a tile that are culled straight from registers (k_raster_span)
+constexpr int DIRECT_MAX = 256;  // records of a tile that are culled straight from registers (k_raster_span) ...
+constexpr int DIRECT_STEPS = 2;  // ... in this many steps per wave (at least DIRECT_MIN lanes each)
+constexpr int DIRECT_MIN = 4;
 constexpr int HZ_SEG = 0, HZ_BLK = 128, HZ_QUAD = 144, HZ_C4 = 148, HZ_SIZE = 404;
 __device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uint32_t *hz, int lane)
 {
@@ -403,17 +405,37 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
     // output (the z resolution is order independent); it only makes the hierarchical early-z below
     // reject more.
     uint4 *__restrict__ ents = a.bins2;
-    // A tile with few records (<= DIRECT_MAX, one per thread) skips the copy altogether: thread (w, lane)
-    // keeps record lane*NW + w in registers and the wave culls its 64 in one step -- no bucket sort, no
-    // bins2 round trip, two barriers less on the chain of a lightly loaded tile.
+    // A tile with few records (<= DIRECT_MAX, at most one per thread) never goes through bins2: the records
+    // are ordered near-first through LDS (the bucket sort below on an exchange buffer that aliases the
+    // phase-1b staging), wave w keeps the records at sorted positions w, w+NW, ... in registers (nearest in
+    // lane 0) and culls them in DIRECT_STEPS steps, so that later steps already see the depths the
+    // nearer triangles left behind.
     const uint32_t nent = c.end - c.beg;
     const bool direct = nent <= (uint32_t)DIRECT_MAX;
     uint4 dent = make_uint4(0, 0, 0, 0);
     bool dvalid = false;
+    int dcount = 0, dpos = 0, dstep = 64; // lanes of this wave that hold a record; next lane to cull; lanes per step
     if (direct) {
-        const uint32_t e = (uint32_t)lane * NW + (uint32_t)w;
-        dvalid = e < nent;
-        if (dvalid) dent = source(e);
+        const bool have = threadIdx.x < nent;
+        const uint4 rec = have ? source(threadIdx.x) : make_uint4(0, 0, 0, 0);
+        const uint32_t bkt = COUNT ? 0u : 63u - ((rec.y >> 21) & 63u);
+        if (have) atomicAdd(&s_bkt[bkt], 1u);
+        __syncthreads();
+        if (w == 0) {
+            const uint32_t x = s_bkt[lane];
+            const uint32_t incl = wave_incl_scan_dpp(x);
+            s_bkt[lane] = incl - x;
+        }
+        __syncthreads();
+        uint4 *exch = reinterpret_cast<uint4 *>(&s_ti[0][0]); // NW * 32 * 32 B >= 256 records
+        if (have) exch[atomicAdd(&s_bkt[bkt], 1u)] = rec;
+        __syncthreads();
+        const uint32_t q = (uint32_t)lane * NW + (uint32_t)w;
+        dvalid = q < nent;
+        if (dvalid) dent = exch[q];
+        dcount = __popcll(__ballot(dvalid));
+        dstep = max(DIRECT_MIN, (dcount + DIRECT_STEPS - 1) / DIRECT_STEPS);
+        __syncthreads(); // the staging is written again by phase 1b
     } else {
         const bool sorted = !COUNT && nent > 2u * B;
         auto bucket_of = [&](const uint4 &e) { return sorted ? 63u - ((e.y >> 21) & 63u) : 0u; };
@@ -462,8 +484,12 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
         if (!input_done && aq_n == 0) { // survivors are processed before more entries are culled (fresh z minima)
             uint32_t e0 = 0;
             bool have = true;
+            int dlo = 0;
             if (direct) {
-                input_done = true; // this wave's records are in `dent`: one step
+                dlo = dpos;
+                dpos += dstep;
+                have = dlo < dcount;
+                if (dpos >= dcount) input_done = true;
             } else {
                 uint32_t b = 0;
                 if (lane == 0) b = atomicAdd(&s_next, 1u);
@@ -483,7 +509,7 @@ __global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUnifor
 #endif
                 }
                 wave_lds_fence();
-                const bool valid = direct ? dvalid : lane < (int)min((uint32_t)SPAN_CULL, c.end - e0);
+                const bool valid = direct ? (dvalid && lane >= dlo && lane < dlo + dstep) : lane < (int)min((uint32_t)SPAN_CULL, c.end - e0);
                 const uint4 en = direct ? dent : (valid ? ents[e0 + lane] : make_uint4(0, 0, 0, 0));
                 const int mnx = (int)(short)(en.z & 0xFFFFu), mny = (int)(short)(en.z >> 16);
                 const int mxx = (int)(short)(en.w & 0xFFFFu), mxy = (int)(short)(en.w >> 16);

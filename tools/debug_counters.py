@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import f_renderer_amd as fr
 from f_renderer_amd import scenes
 W, H, n = 1920, 1080, 1_000_000
+if len(sys.argv) > 3: W, H, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 tris = scenes.random_clip_triangles(n, W, H)
 r = fr.Renderer(W, H)
 m = r.upload_mesh(tris, fr.VS_CLIP)
