@@ -671,13 +671,22 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
                         for (int q = 0; q < 9; ++q) put(pos[q], mine);
                     }
                 }
+                // larger footprints: four at a time, each spread over a quarter of the wave (16 lanes)
                 unsigned long long big = __ballot(nt > 0 && !small && !mid);
                 while (big) {
-                    const int src = __builtin_ctzll(big);
-                    big &= big - 1;
-                    const int bx0 = __shfl(t.tx0, src), by0 = __shfl(t.ty0, src), bnx = __shfl(ntx, src), bnt = __shfl(nt, src);
-                    const uint4 ent = make_uint4(base + src, __shfl(pb[k].z, src), __shfl(pb[k].x, src), __shfl(pb[k].y, src));
-                    for (int q = lane; q < bnt; q += 64) visit(ent, bx0 + q % bnx, by0 + q / bnx);
+                    int src = -1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int sj = big ? __builtin_ctzll(big) : -1;
+                        big &= big - 1;                    // (0 stays 0)
+                        if ((lane >> 4) == j) src = sj;
+                    }
+                    const int sl = src < 0 ? 0 : src;
+                    const int bx0 = __shfl(t.tx0, sl), by0 = __shfl(t.ty0, sl), bnx = __shfl(ntx, sl);
+                    const int bnt_src = __shfl(nt, sl); // unconditional: a cross-lane read must not sit under `src >= 0` (inactive source lanes read as 0)
+                    const int bnt = src < 0 ? 0 : bnt_src;
+                    const uint4 ent = make_uint4(base + sl, __shfl(pb[k].z, sl), __shfl(pb[k].x, sl), __shfl(pb[k].y, sl));
+                    for (int q = lane & 15; q < bnt; q += 16) visit(ent, bx0 + q % bnx, by0 + q / bnx);
                 }
             }
         }
