@@ -141,3 +141,27 @@ def test_baseline_config_full_size_bit_exact(oracle, name):
         np.testing.assert_array_equal(c, f.color)
     assert st["frag_covered"] == oc["frag_covered"] and st["tris_setup"] == oc["tris_setup"]
     r.close()
+
+
+def test_three_million_triangles_take_the_large_mesh_paths(oracle):
+    """3,000,000 triangles at 1920x1080: more than 8192 count blocks (k_scan_blocks between count and emit),
+    bin chunks of ~11.7K triangles (several rounds per workgroup, regions larger than the LDS staging) and
+    tiles with ~2,600 records (the sorted path's overflow loops) -- bit for bit against the oracle."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    n = 3_000_000
+    tris = scenes.random_clip_triangles(n, W, H, seed=31)
+    r = fr.Renderer(W, H)
+    r.clear()
+    r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
+    _, d, t = r.readback()
+    st = r.stats()
+    f = oracle.Frame(W, H)
+    f.clear()
+    f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
+    oc = f.counters.as_dict()
+    assert oc["frag_nan"] == 0 and st["frag_nan"] == 0
+    np.testing.assert_array_equal(t, f.tri_id)
+    np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+    assert st["frag_covered"] == oc["frag_covered"] and st["tris_setup"] == oc["tris_setup"]
+    r.close()
