@@ -186,7 +186,8 @@ def main():
             raise SystemExit("device work list overflow during warmup")
 
         r.profile_reset()
-        r.profile_enable(True, kernels=["k_raster"])  # HIP events around the dominant kernel only
+        PROF_PERIOD = 4  # HIP events around the dominant kernel only, every 4th launch (a pair costs the stream ~4 us)
+        r.profile_enable(True, kernels=["k_raster"], period=PROF_PERIOD)
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -254,7 +255,7 @@ def main():
                                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                     "traffic": load_pmc_traffic(args.workload),
                                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg_ms, 5),
-                                    "launches": raster_n, "frag_zpass": f_pass}
+                                    "launches": raster_n, "sampled_every": PROF_PERIOD, "frag_zpass": f_pass}
             else:
                 line["roofline"] = {"bound": "hbm", "kernel": "k_raster", "achieved": None, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 5),

@@ -109,6 +109,7 @@ SIGNATURES = {
     "frr_event_record": (C.c_int, [C.c_void_p, C.c_int]),
     "frr_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_float)]),
     "frr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "frr_profile_set_period": (C.c_int, [C.c_void_p, C.c_uint32]),
     "frr_profile_reset": (C.c_int, [C.c_void_p]),
     "frr_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_float), _P(C.c_uint32)]),
     "frr_set_identity": (None, [_P(C.c_float)]),

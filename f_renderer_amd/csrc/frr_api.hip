@@ -89,6 +89,8 @@ struct frr_ctx {
     uint32_t prof_mask = 0;   // bit per KernelId
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
+    uint32_t prof_period = 1;         // bracket only every prof_period-th launch of a kernel (frr_profile_set_period)
+    uint32_t prof_seen[KID_COUNT] = {};
     double prof_ms[KID_COUNT] = {};
     uint32_t prof_n[KID_COUNT] = {};
     std::string err;
@@ -131,7 +133,7 @@ struct ProfScope {
     frr_ctx *c; int kid; hipEvent_t a = nullptr;
     ProfScope(frr_ctx *c_, int kid_) : c(c_), kid(kid_)
     {
-        if (c->prof_mask & (1u << kid)) { a = get_event(c); (void)hipEventRecord(a, c->stream); }
+        if ((c->prof_mask & (1u << kid)) && (c->prof_seen[kid]++ % c->prof_period) == 0) { a = get_event(c); (void)hipEventRecord(a, c->stream); }
     }
     ~ProfScope()
     {
@@ -747,6 +749,13 @@ int frr_profile_enable(frr_ctx *c, int enable)
     if (!c) return FRR_ERR_INVALID;
     prof_collect(c);
     c->prof_mask = enable < 0 ? 0xFFFFFFFFu : (uint32_t)enable;
+    return FRR_OK;
+}
+int frr_profile_set_period(frr_ctx *c, uint32_t period)
+{
+    if (!c || period == 0) return FRR_ERR_INVALID;
+    c->prof_period = period;
+    for (int i = 0; i < KID_COUNT; ++i) c->prof_seen[i] = 0;
     return FRR_OK;
 }
 int frr_profile_reset(frr_ctx *c)

@@ -276,9 +276,11 @@ class Renderer:
     KERNELS = ("k_clear", "k_geom_count", "k_scan_blocks", "k_geom_emit", "k_bin_count",
                "k_tile_scan", "k_bin_fill", "k_raster", "k_bin_seg")
 
-    def profile_enable(self, on=True, kernels=None):
-        """Bracket launches with HIP events: all kernels (on=True), none (False) or the named ones."""
+    def profile_enable(self, on=True, kernels=None, period=1):
+        """Bracket launches with HIP events: all kernels (on=True), none (False) or the named ones; only every
+        `period`-th launch of each (an event pair costs the stream ~4 us)."""
         mask = (-1 if on else 0) if kernels is None else sum(1 << self.KERNELS.index(k) for k in kernels)
+        self._check(self._lib.frr_profile_set_period(self._ctx, period))
         self._check(self._lib.frr_profile_enable(self._ctx, mask))
 
     def profile_reset(self):

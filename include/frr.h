@@ -180,6 +180,10 @@ int frr_event_elapsed_ms(frr_ctx *ctx, int a, int b, float *ms);
  * k_geom_count, k_scan_blocks, k_geom_emit, k_bin_count, k_tile_scan, k_bin_fill, k_raster,
  * k_bin_seg.  A profiled launch is bracketed by two HIP events on the ctx stream. */
 int frr_profile_enable(frr_ctx *ctx, int mask);
+/* bracket only every `period`-th launch of each selected kernel (default 1): an event pair costs the
+ * stream ~4 us, which matters when the whole frame is 150 us; frr_profile_get then reports the sampled
+ * launches. */
+int frr_profile_set_period(frr_ctx *ctx, uint32_t period);
 int frr_profile_reset(frr_ctx *ctx);
 int frr_profile_get(frr_ctx *ctx, const char *kernel, float *total_ms, uint32_t *launches);
 

@@ -25,3 +25,6 @@ def run(k, nctx):
 for nctx in (1, 2):
     run(20, nctx)
     print(f"{nctx} context(s): {run(200, nctx):.1f} us/frame")
+rs[0][0].profile_enable(True, kernels=["k_raster"])
+run(20, 1)
+print(f"1 context, HIP events around the tile kernel: {run(200, 1):.1f} us/frame")
