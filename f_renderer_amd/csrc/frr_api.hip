@@ -45,9 +45,15 @@ struct frr_ctx {
     Counters *cnt = nullptr;
     // geometry workspace
     uint32_t *block_sums = nullptr; size_t block_sums_cap = 0;
-    uint32_t *group_sums = nullptr; size_t group_sums_cap = 0; // two slots of 128 padded group counters (GeomArgs)
+    uint32_t *group_sums = nullptr; size_t group_sums_cap = 0; // four slots of 128 padded group counters (GeomArgs)
+    uint32_t *block_sums_g = nullptr; size_t block_sums_g_cap = 0; // dense-owned draws: per-block sums over ALL triangles
+    uint32_t *gidx = nullptr; size_t gidx_cap = 0;                 // dense-owned draws: emission index of each setup slot
+    uint2 *fast_list = nullptr; size_t fast_list_cap = 0;         // dense-owned draws: per count block, its owned unclipped triangles
+    uint32_t *fast_count = nullptr; size_t fast_count_cap = 0;
+    bool geom_dense = false;   // the latest frr_geometry/frr_draw was dense-owned
+    bool geom_no_dense = false; // FRR_GEOM=nodense: partitioned draws keep a slot for every triangle (tests)
     int geom_slot = 0;         // group_sums slot of the latest draw (alternates)
-    uint2 *clip_list = nullptr; size_t clip_list_cap = 0;     // clipped triangles of the current draw (k_geom_count -> k_geom_emit)
+    uint4 *clip_list = nullptr; size_t clip_list_cap = 0;     // clipped triangles of the current draw (k_geom_count -> k_geom_emit)
     int bin_g = 0;             // FRR_BIN_G: override the number of binning chunks (dev)
     uint32_t ent_slot_override = 0; // FRR_ENT_SLOT: per-tile slot of bins2 in records (tests of the overflow arena)
     // frr_clear is deferred: the first full-window draw of the span kernel performs it inside the tile kernel
@@ -283,7 +289,7 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     c->device = device; c->W = width; c->H = height;
     { const char *e = getenv("FRR_RASTER"); c->raster_sweep = e && strcmp(e, "sweep") == 0; }
     { const char *e = getenv("FRR_RASTER_NW"); const int v = e ? atoi(e) : 0; c->raster_nw = (v == 4 || v == 8 || v == 16) ? v : 0; }
-    { const char *e = getenv("FRR_GEOM"); c->geom_force_scan = e && strcmp(e, "scan") == 0; }
+    { const char *e = getenv("FRR_GEOM"); c->geom_force_scan = e && strcmp(e, "scan") == 0; c->geom_no_dense = e && strcmp(e, "nodense") == 0; }
     { const char *e = getenv("FRR_BIN_G"); c->bin_g = e ? atoi(e) : 0; }
     { const char *e = getenv("FRR_CLEAR"); c->clear_eager = e && strcmp(e, "eager") == 0; }
     { const char *e = getenv("FRR_ENT_SLOT"); c->ent_slot_override = e ? (uint32_t)atoi(e) : 0u; }
@@ -326,7 +332,7 @@ void frr_destroy(frr_ctx *c)
     prof_collect(c);
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
-    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->group_sums, c->clip_list, c->recs, c->vary, c->pbox,
+    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->group_sums, c->block_sums_g, c->gidx, c->fast_list, c->fast_count, c->clip_list, c->recs, c->vary, c->pbox,
                     c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bins2, c->bin_matrix};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -514,13 +520,27 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     g.selfsum = 0;
     g.reset_frame = c->counters_pending ? 1 : 0;
     c->counters_pending = false;
+    constexpr size_t kGroupSlot = (size_t)128 * GROUP_PAD; // 4 slots: {owned, all triangles} x {this draw, previous draw}
     if (!c->group_sums) {
-        if ((rc = ensure(c, c->group_sums, c->group_sums_cap, (size_t)2 * 128 * GROUP_PAD)) != FRR_OK) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->group_sums, 0, (size_t)2 * 128 * GROUP_PAD * sizeof(uint32_t), c->stream));
+        if ((rc = ensure(c, c->group_sums, c->group_sums_cap, 4 * kGroupSlot)) != FRR_OK) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->group_sums, 0, 4 * kGroupSlot * sizeof(uint32_t), c->stream));
     }
     c->geom_slot ^= 1;
-    g.group_sums = c->group_sums + (size_t)c->geom_slot * 128 * GROUP_PAD;
-    g.group_zero = c->group_sums + (size_t)(c->geom_slot ^ 1) * 128 * GROUP_PAD;
+    g.group_sums = c->group_sums + (size_t)c->geom_slot * kGroupSlot;
+    g.group_zero = c->group_sums + (size_t)(c->geom_slot ^ 1) * kGroupSlot;
+    g.group_sums_g = c->group_sums + (size_t)(2 + c->geom_slot) * kGroupSlot;
+    g.group_zero_g = c->group_sums + (size_t)(2 + (c->geom_slot ^ 1)) * kGroupSlot;
+    // dense-owned draw: partitioned ctx + frr_draw (the window is known) + a mesh the emit blocks can offset themselves
+    g.dense = (filter && c->world > 1 && nblocks <= 8192 && !c->geom_force_scan && !c->geom_no_dense) ? 1 : 0;
+    g.block_sums_g = nullptr; g.gidx = nullptr; g.fast_list = nullptr; g.fast_count = nullptr;
+    if (g.dense) {
+        if ((rc = ensure(c, c->block_sums_g, c->block_sums_g_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
+        if ((rc = ensure(c, c->gidx, c->gidx_cap, c->setup_cap)) != FRR_OK) return rc;
+        if ((rc = ensure(c, c->fast_list, c->fast_list_cap, (size_t)nblocks * GEOM_BLOCK)) != FRR_OK) return rc;
+        if ((rc = ensure(c, c->fast_count, c->fast_count_cap, (size_t)nblocks)) != FRR_OK) return rc;
+        g.block_sums_g = c->block_sums_g; g.gidx = c->gidx; g.fast_list = c->fast_list; g.fast_count = c->fast_count;
+    }
+    c->geom_dense = g.dense != 0;
     g.part_rank = c->rank; g.part_world = filter ? c->world : 1; g.part_y0 = fy0; g.part_y1 = fy1;
     g.part_rpr = 0;
     if (filter && c->part_blocked) {
@@ -580,6 +600,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     a.rank = c->rank; a.world = c->world;
     a.rpr = (c->part_blocked && c->world > 1) ? std::max(1, (a.tiles_y + c->world - 1) / c->world) : 0;
     a.recs = c->recs; a.vary = c->vary; a.pbox = c->pbox;
+    a.gidx = c->geom_dense ? c->gidx : nullptr;
     a.tile_counts = c->tile_counts; a.tile_offsets = c->tile_offsets; a.tile_cursor = c->tile_cursor;
     const uint32_t ntiles = (uint32_t)a.tiles_x * a.tiles_y;
     int rc;
@@ -716,7 +737,7 @@ int frr_get_stats(frr_ctx *c, frr_stats *out)
     HIP_TRY(c, hipMemcpyAsync(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     out->tris_in = h.tris_in;
-    out->tris_setup = (uint64_t)h.tri_base + h.n_setup;
+    out->tris_setup = (uint64_t)h.tri_base + h.n_emit;
     out->bin_entries = h.bin_entries_frame + h.seg_total[0] + h.seg_total[1];
     out->frag_covered = h.frag_covered;
     out->frag_nan = h.frag_nan;

@@ -26,7 +26,7 @@ static_assert(sizeof(RasterRec) == 64, "one cache line per triangle");
 
 struct Counters {
     uint32_t n_setup;       // setup triangles of the current draw
-    uint32_t reserved0;
+    uint32_t n_emit;        // triangles the current draw emits in the reference's numbering (== n_setup unless the draw is dense-owned)
     uint32_t tri_base;      // emission index of this draw's first triangle within the frame
     uint32_t overflow;      // bit0 setup capacity, bit1 bin capacity
     uint64_t bin_total;     // (triangle,tile) pairs of the current draw
@@ -70,8 +70,18 @@ struct GeomArgs {
     int32_t part_rank, part_world; // tile-row ownership filter (world == 1: none); only set by frr_draw,
     int32_t part_y0, part_y1;      // which knows the raster window's height range
     int32_t part_rpr;              // > 0: blocked partition (RasterArgs::rpr)
+    // Dense-owned draws (partitioned ctx, frr_draw, <= 8192 count blocks): triangles that touch none of the
+    // rank's tile rows get NO setup slot at all -- offsets come from the sums of the owned triangles
+    // (block_sums / group_sums), the reference's emission index of every slot is kept in gidx[] and derived
+    // from the sums over all triangles (block_sums_g / group_sums_g).  Binning and the tile kernel then see
+    // 1/N of the triangles; ids and z tie-breaks are unchanged (the dense order is the emission order).
+    int32_t dense;
+    uint32_t *block_sums_g, *group_sums_g, *group_zero_g;
+    uint32_t *gidx;                // [cap] emission index (within the draw) of each setup slot
+    uint2 *fast_list;              // [nblocks][256] per count block: its owned, unclipped triangles (thread | offset in block << 8, emission offset in block)
+    uint32_t *fast_count;          // [nblocks]
     uint32_t *block_sums;   // [nblocks] setup triangles per count block; exclusive-scanned in place by k_scan_blocks (MODE 0)
-    uint2 *clip_list;       // [<= ntris] clipped triangles of this draw: (input index, offset within its block | fan size << 16)
+    uint4 *clip_list;       // [<= ntris] clipped triangles of this draw: (input index, offset within its block | fan size << 16, emission offset within its block, 0)
     int32_t cslot;          // Counters::clip_n slot of this draw
     RasterRec *recs;
     float *vary;
@@ -89,6 +99,7 @@ struct RasterArgs {
     const RasterRec *recs;
     const float *vary;
     const uint4 *pbox;                // see GeomArgs::pbox
+    const uint32_t *gidx;             // dense-owned draws: emission index of each setup slot (else null: the slot index)
     uint32_t *tile_counts;            // [ntiles]
     uint32_t *tile_offsets;           // [ntiles+1]
     uint32_t *tile_cursor;            // [ntiles]
@@ -119,7 +130,7 @@ __device__ __forceinline__ bool owns_tile_row(int ty, int rank, int world, int r
 // what frr_clear does to the counters (by k_clear, or deferred to the next draw's bookkeeping thread)
 __device__ __forceinline__ void reset_frame_counters(Counters *cnt)
 {
-    cnt->n_setup = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
+    cnt->n_setup = 0; cnt->n_emit = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
     cnt->seg_total[0] = cnt->seg_total[1] = 0ull; cnt->ent_cursor[0] = cnt->ent_cursor[1] = 0u;
     cnt->frag_covered = 0; cnt->frag_nan = 0; cnt->tris_in = 0; cnt->bin_entries_frame = 0; cnt->draws = 0;
     for (int k = 0; k < 12; ++k) cnt->dbg[k] = 0;
@@ -259,6 +270,19 @@ __device__ __forceinline__ ScreenVtx to_screen(const float pos[4], float fw, flo
     v.ix = f32_as_i32(v.sx + 0.5f);
     v.iy = f32_as_i32(v.sy + 0.5f);
     return v;
+}
+// Multi-GPU: does a (not clipped) triangle with snapped corner rows iy0..iy2 touch a tile row this rank owns?
+// (used identically by k_geom_count and k_geom_emit: the two must agree on every triangle)
+__device__ __forceinline__ bool tri_rows_owned(const GeomArgs &g, int iy0, int iy1, int iy2)
+{
+    if (g.part_world <= 1) return true;
+    const int miny = clampi(min(iy0, min(iy1, iy2)), g.part_y0, g.part_y1);
+    const int maxy = clampi(max(iy0, max(iy1, iy2)), g.part_y0, g.part_y1);
+    if (maxy <= miny) return false;
+    const int ty0 = (miny - g.part_y0) / TILE, ty1 = (maxy - 1 - g.part_y0) / TILE;
+    if (g.part_rpr > 0) return ty0 < (g.part_rank + 1) * g.part_rpr && ty1 >= g.part_rank * g.part_rpr;
+    const int first = ty0 + ((g.part_rank - ty0 % g.part_world) + g.part_world) % g.part_world;
+    return first <= ty1;
 }
 // renderer.rs:26-29
 __device__ __forceinline__ bool is_top_left(int ax, int ay, int bx, int by)

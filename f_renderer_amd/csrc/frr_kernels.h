@@ -76,11 +76,13 @@ __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t *s_w
 template <int VS>
 __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_count(GeomArgs g, DevUniforms u)
 {
-    __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_nclip, s_cbase;
+    __shared__ uint32_t s_w[4], s_wg[4];
+    __shared__ uint32_t s_nclip, s_cbase, s_nfast;
     constexpr int NF = VSInfo<VS>::NF;
     const uint32_t t = blockIdx.x * GEOM_BLOCK + threadIdx.x;
-    uint32_t n = 0;
+    if (threadIdx.x == 0) s_nfast = 0; // (ordered like s_nclip)
+    uint32_t n = 0;    // triangles this input emits (the reference's count)
+    uint32_t nl = 0;   // ... of which this rank keeps a setup slot (dense-owned draws: none for unowned triangles)
     bool clipped = false;
     if (threadIdx.x == 0) s_nclip = 0; // ordered before its use by the barrier inside block_excl_scan256
     if (t < g.ntris) {
@@ -89,21 +91,33 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_count(GeomArgs g, DevUnifor
 #pragma unroll
         for (int v = 0; v < 3; ++v) run_vs<VS, false>(u, in + v * NF, pos[v], nullptr);
         n = classify(pos, clipped);
+        nl = n;
+        if (g.dense && n != 0u && !clipped) {
+            const float fw = (float)g.width, fh = (float)g.height;
+            const ScreenVtx s0 = to_screen(pos[0], fw, fh), s1 = to_screen(pos[1], fw, fh), s2 = to_screen(pos[2], fw, fh);
+            if (!tri_rows_owned(g, s0.iy, s1.iy, s2.iy)) nl = 0u;
+        }
     }
-    uint32_t total;
-    const uint32_t off_local = block_excl_scan256(n, s_w, total);
-    if (threadIdx.x == 0) g.block_sums[blockIdx.x] = total;
+    uint32_t total, total_g = 0, goff_local = 0;
+    const uint32_t off_local = block_excl_scan256(nl, s_w, total);
+    if (g.dense) goff_local = block_excl_scan256(n, s_wg, total_g);
+    if (threadIdx.x == 0) { g.block_sums[blockIdx.x] = total; if (g.dense) g.block_sums_g[blockIdx.x] = total_g; }
     // clipped triangles that emit anything go on the draw's global list: (input index, offset within the
     // block | fan size << 16); one returning atomic per block that has any
     const bool listed = clipped && n != 0u;
     uint32_t crank = 0;
     if (listed) crank = atomicAdd(&s_nclip, 1u);
+    // dense-owned draws: the block's owned, unclipped triangles are listed too (any order: each entry carries
+    // its offsets), so that k_geom_emit touches only those -- 1/N of the inputs on a rank of N
+    const bool fast = g.dense && nl != 0u && !clipped;
+    if (fast) g.fast_list[(size_t)blockIdx.x * GEOM_BLOCK + atomicAdd(&s_nfast, 1u)] = make_uint2(threadIdx.x | (off_local << 8), goff_local);
     __syncthreads();
+    if (g.dense && threadIdx.x == 0) g.fast_count[blockIdx.x] = s_nfast;
     const uint32_t nclip = s_nclip;
     if (nclip) {
         if (threadIdx.x == 0) s_cbase = atomicAdd(&g.cnt->clip_n[g.cslot], nclip);
         __syncthreads();
-        if (listed) g.clip_list[s_cbase + crank] = make_uint2(t, off_local | (n << 16));
+        if (listed) g.clip_list[s_cbase + crank] = make_uint4(t, off_local | (n << 16), goff_local, 0u);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) g.cnt->clip_n[g.cslot ^ 1] = 0u; // the previous draw's list, for the next draw
     if (g.selfsum) {
@@ -112,10 +126,14 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_count(GeomArgs g, DevUnifor
         // draw, is zeroed for the next one
         if (threadIdx.x == 0 && total) atomicAdd(&g.group_sums[(blockIdx.x >> 6) * GROUP_PAD], total);
         if (blockIdx.x == 0 && threadIdx.x < 128) g.group_zero[threadIdx.x * GROUP_PAD] = 0u;
+        if (g.dense) {
+            if (threadIdx.x == 0 && total_g) atomicAdd(&g.group_sums_g[(blockIdx.x >> 6) * GROUP_PAD], total_g);
+            if (blockIdx.x == 0 && threadIdx.x < 128) g.group_zero_g[threadIdx.x * GROUP_PAD] = 0u;
+        }
     }
     if (g.selfsum && blockIdx.x == 0 && threadIdx.x == 0) { // per-draw bookkeeping k_scan_blocks would do
         if (g.reset_frame) reset_frame_counters(g.cnt);
-        g.cnt->tri_base += g.cnt->n_setup;                  // previous draw's triangles precede this draw's
+        g.cnt->tri_base += g.cnt->n_emit;                   // previous draw's triangles precede this draw's
         g.cnt->tris_in += g.ntris;
         g.cnt->draws += 1;
     }
@@ -148,10 +166,11 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *__restrict__ sum
     if (threadIdx.x == 0) {
         uint32_t total = s_carry;
         if (reset_frame) reset_frame_counters(cnt);
-        cnt->tri_base += cnt->n_setup; // previous draw's triangles precede this draw's in the frame
+        cnt->tri_base += cnt->n_emit; // previous draw's triangles precede this draw's in the frame
         cnt->need_setup = total;
         if (total > cap) { cnt->overflow |= 1u; total = 0; }
         cnt->n_setup = total;
+        cnt->n_emit = total;
         cnt->tris_in += ntris;
         cnt->draws += 1;
     }
@@ -174,7 +193,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *__restrict__ sum
 constexpr int CLIP_MAXV = 21;
 
 template <int VS>
-__device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevUniforms &u, uint32_t t, uint32_t off, int lane,
+__device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevUniforms &u, uint32_t t, uint32_t off, uint32_t goff, int lane,
                                                    float (*s_xy)[2], int32_t *s_key, float (*s_v)[7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)])
 {
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K, KS = K > 0 ? K : 1;
@@ -247,6 +266,7 @@ __device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevU
         flags |= is_top_left(p1x, p1y, p2x, p2y) ? 0u : 4u;
         flags |= is_top_left(p2x, p2y, p0x, p0y) ? 0u : 8u;
         const uint32_t idx = off + (uint32_t)q;
+        if (g.dense) g.gidx[idx] = goff + (uint32_t)q;
         { const uint2 pb = pack_pbox(p0x, p0y, p1x, p1y, p2x, p2y); g.pbox[idx] = make_uint4(pb.x, pb.y, cull_zub(v0[0], v1[0], v2[0]), 0u); }
         uint4 *dst = reinterpret_cast<uint4 *>(g.recs + idx);
         dst[0] = make_uint4((uint32_t)p0x, (uint32_t)p0y, (uint32_t)p1x, (uint32_t)p1y);
@@ -267,72 +287,94 @@ __device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevU
 template <int VS, int MODE>
 __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniforms u)
 {
-    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_w[4], s_wg[4];
     __shared__ uint4 s_stage[GEOM_BLOCK / 64][64 * 5];    // per wave: 64 records at an 80-byte stride (see the record stores)
     __shared__ float s_cxy[GEOM_BLOCK / 64][CLIP_MAXV][2]; // per wave: clip x,y in list order
     __shared__ int32_t s_ckey[GEOM_BLOCK / 64][CLIP_MAXV];
     __shared__ float s_cv[GEOM_BLOCK / 64][CLIP_MAXV][7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)];
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K;
     const uint32_t bid = blockIdx.x;
-    const uint32_t t = bid * GEOM_BLOCK + threadIdx.x;
     float pos[3][4];
     float ctx[3][K > 0 ? K : 1];
-    uint32_t n = 0;
+    uint32_t n = 0;   // the reference's count for this input
+    uint32_t nl = 0;  // setup slots this rank keeps for it
     bool clipped = false;
-    if (t < g.ntris) {
-        const float *in = g.in + (size_t)t * (3 * NF);
+    ScreenVtx s0 = {}, s1 = {}, s2 = {};
+    bool owned = true;
+    uint32_t total, total_g = 0, goff = 0, off;
+    if (MODE == 2 && g.dense) {
+        // dense-owned draw: thread j takes the j-th entry of the block's list of owned, unclipped triangles
+        // (k_geom_count); everything else of the block needs no work here
+        const uint32_t cntf = g.fast_count[bid];
+        total = g.block_sums[bid];
+        total_g = g.block_sums_g[bid];
+        off = 0;
+        if (threadIdx.x < cntf) {
+            const uint2 e = g.fast_list[(size_t)bid * GEOM_BLOCK + threadIdx.x];
+            const uint32_t t = bid * GEOM_BLOCK + (e.x & 255u);
+            const float *in = g.in + (size_t)t * (3 * NF);
 #pragma unroll
-        for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
-        n = classify(pos, clipped);
+            for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
+            const float fw = (float)g.width, fh = (float)g.height;
+            s0 = to_screen(pos[0], fw, fh); s1 = to_screen(pos[1], fw, fh); s2 = to_screen(pos[2], fw, fh);
+            n = nl = 1u;
+            off = e.x >> 8;
+            goff = e.y;
+        }
+    } else {
+        const uint32_t t = bid * GEOM_BLOCK + threadIdx.x;
+        if (t < g.ntris) {
+            const float *in = g.in + (size_t)t * (3 * NF);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
+            n = classify(pos, clipped);
+            nl = n;
+            if (n != 0u && !clipped) {
+                const float fw = (float)g.width, fh = (float)g.height;
+                s0 = to_screen(pos[0], fw, fh); s1 = to_screen(pos[1], fw, fh); s2 = to_screen(pos[2], fw, fh);
+                // Multi-GPU: a rank that owns none of the tile rows this triangle's bbox touches never reads its
+                // record (geometry is replicated, so this is what keeps the replicated part small)
+                owned = tri_rows_owned(g, s0.iy, s1.iy, s2.iy);
+            }
+        }
+        off = block_excl_scan256(nl, s_w, total);
     }
-    uint32_t total;
-    uint32_t off = block_excl_scan256(n, s_w, total);
     if constexpr (MODE == 2) {
         // exclusive prefix of this block = groups before its group (<= 127 counters, threads 0..126)
         // + the blocks before it in its own group (<= 63 block sums, threads 128..190): one load per thread
-        uint32_t part = 0;
+        // (two in a dense-owned draw: the same sums over ALL triangles give the emission indices)
+        uint32_t part = 0, part_g = 0;
         const uint32_t grp = bid >> 6, inb = bid & 63u;
-        if (threadIdx.x < grp) part = g.group_sums[threadIdx.x * GROUP_PAD];
-        else if (threadIdx.x >= 128u && threadIdx.x - 128u < inb) part = g.block_sums[(grp << 6) + threadIdx.x - 128u];
+        if (threadIdx.x < grp) {
+            part = g.group_sums[threadIdx.x * GROUP_PAD];
+            if (g.dense) part_g = g.group_sums_g[threadIdx.x * GROUP_PAD];
+        } else if (threadIdx.x >= 128u && threadIdx.x - 128u < inb) {
+            part = g.block_sums[(grp << 6) + threadIdx.x - 128u];
+            if (g.dense) part_g = g.block_sums_g[(grp << 6) + threadIdx.x - 128u];
+        }
         const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(part), 63);
-        __syncthreads();                       // s_w was read by block_excl_scan256 above
-        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = wsum;
+        const uint32_t wsum_g = g.dense ? (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(part_g), 63) : 0u;
+        __syncthreads();                       // s_w / s_wg were read by block_excl_scan256 above
+        if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = wsum; s_wg[threadIdx.x >> 6] = wsum_g; }
         __syncthreads();
         const uint32_t excl = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        const uint32_t excl_g = s_wg[0] + s_wg[1] + s_wg[2] + s_wg[3];
         off += excl;
-        if (threadIdx.x == 0 && bid == gridDim.x - 1) { // the last block knows the grand total
+        goff += excl_g;
+        if (threadIdx.x == 0 && bid == gridDim.x - 1) { // the last block knows the grand totals
             const uint32_t all = excl + total;
             g.cnt->need_setup = all;
             if (all > g.cap) atomicOr(&g.cnt->overflow, 1u);
             g.cnt->n_setup = all > g.cap ? 0u : all;
+            g.cnt->n_emit = g.dense ? excl_g + total_g : (all > g.cap ? 0u : all);
         }
     } else {
         off += g.block_sums[blockIdx.x];
     }
-    // nothing to emit (None / dropped) or capacity overflow (the frame is flagged invalid)
-    const bool emit_ok = n != 0 && (MODE != 0 ? off + n <= g.cap : g.cnt->n_setup != 0u);
+    // nothing to emit (None / dropped / not this rank's) or capacity overflow (the frame is flagged invalid)
+    const bool emit_ok = nl != 0 && (MODE != 0 ? off + nl <= g.cap : g.cnt->n_setup != 0u);
     if (emit_ok && !clipped) { // (clipped triangles: the draw's list, below)
-    const float fw = (float)g.width, fh = (float)g.height;
-    const ScreenVtx s0 = to_screen(pos[0], fw, fh), s1 = to_screen(pos[1], fw, fh), s2 = to_screen(pos[2], fw, fh);
-    // Multi-GPU: a rank that owns none of the tile rows this triangle's bbox touches never reads its
-    // record; it only leaves an empty bbox for the binning passes (geometry is replicated, so this
-    // is what keeps the replicated part small).
-    bool owned = true;
-    if (g.part_world > 1) {
-        const int miny = clampi(min(s0.iy, min(s1.iy, s2.iy)), g.part_y0, g.part_y1);
-        const int maxy = clampi(max(s0.iy, max(s1.iy, s2.iy)), g.part_y0, g.part_y1);
-        owned = false;
-        if (maxy > miny) {
-            const int ty0 = (miny - g.part_y0) / TILE, ty1 = (maxy - 1 - g.part_y0) / TILE;
-            if (g.part_rpr > 0) {
-                owned = ty0 < (g.part_rank + 1) * g.part_rpr && ty1 >= g.part_rank * g.part_rpr;
-            } else {
-                const int first = ty0 + ((g.part_rank - ty0 % g.part_world) + g.part_world) % g.part_world;
-                owned = first <= ty1;
-            }
-        }
-        if (!owned) g.pbox[off] = make_uint4(0u, 0u, 0u, 0u);
-    }
+    if (!owned) g.pbox[off] = make_uint4(0u, 0u, 0u, 0u); // not dense: the slot exists but stays empty for the binning
     if (owned) {
     // centroid (:180-187), n == 3
     float cx = 0.0f, cy = 0.0f;
@@ -403,24 +445,30 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
     const uint4 q1 = make_uint4((uint32_t)px[2], (uint32_t)py[2], f2u(sx[0]), f2u(sy[0]));
     const uint4 q2 = make_uint4(f2u(sx[1]), f2u(sy[1]), f2u(sx[2]), f2u(sy[2]));
     const uint4 q3 = make_uint4(f2u(rw[0]), f2u(rw[1]), f2u(rw[2]), flags);
-    if (__ballot(true) == ~0ull) {
-        // All 64 lanes of the wave are here: each emits exactly one triangle, so their records are
-        // consecutive in memory.  A lane-per-record store writes 16 B at a 64-B stride (64 partial-line
-        // writes per instruction, write-through); staged through LDS (80-B record stride: conflict-free
-        // b128 writes) the same 4 KB leave as four fully coalesced 1-KB stores.
-        uint4 *st = s_stage[threadIdx.x >> 6];
-        const int ln = threadIdx.x & 63;
-        st[ln * 5 + 0] = q0; st[ln * 5 + 1] = q1; st[ln * 5 + 2] = q2; st[ln * 5 + 3] = q3;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint4 *dst = reinterpret_cast<uint4 *>(g.recs + __builtin_amdgcn_readfirstlane(off));
+    {
+        // The lanes that are here emit exactly one triangle each; unless a clipped triangle sits between them
+        // their records are consecutive in memory.  A lane-per-record store writes 16 B at a 64-B stride (64
+        // partial-line writes per instruction, write-through); staged through LDS (80-B record stride:
+        // conflict-free b128 writes) the same bytes leave as fully coalesced stores.
+        const unsigned long long am = __ballot(true);
+        const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+        const int np = __popcll(am);
+        const uint32_t off0 = __builtin_amdgcn_readfirstlane(off);
+        if (__ballot(off == off0 + (uint32_t)rk) == am) {
+            uint4 *st = s_stage[threadIdx.x >> 6];
+            st[rk * 5 + 0] = q0; st[rk * 5 + 1] = q1; st[rk * 5 + 2] = q2; st[rk * 5 + 3] = q3;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint4 *dst = reinterpret_cast<uint4 *>(g.recs + off0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int c = i * 64 + ln; dst[c] = st[(c >> 2) * 5 + (c & 3)]; }
-    } else {
-        uint4 *dst = reinterpret_cast<uint4 *>(g.recs + off);
-        dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
+            for (int j = 0; j < 4; ++j) { const int c = rk + j * np; dst[c] = st[(c >> 2) * 5 + (c & 3)]; }
+        } else {
+            uint4 *dst = reinterpret_cast<uint4 *>(g.recs + off);
+            dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
+        }
     }
+    if (g.dense) g.gidx[off] = goff;
     if constexpr (K > 0) {
         float *o = g.vary + (size_t)off * (3 * K);
 #pragma unroll
@@ -437,22 +485,28 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniform
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         const uint32_t nwaves = gridDim.x * (GEOM_BLOCK / 64);
         for (uint32_t e = bid * (GEOM_BLOCK / 64) + (uint32_t)w; e < nclip; e += nwaves) {
-            const uint2 en = g.clip_list[e];
+            const uint4 en = g.clip_list[e];
             const uint32_t ct = en.x, cn = en.y >> 16, cb = ct / GEOM_BLOCK;
-            uint32_t base;
+            uint32_t base, gbase = 0;
             if constexpr (MODE == 2) {
                 const uint32_t grp = cb >> 6, inb = cb & 63u;
-                uint32_t part = 0;
+                uint32_t part = 0, part_g = 0;
                 if ((uint32_t)lane < grp) part += g.group_sums[lane * GROUP_PAD];
                 if ((uint32_t)lane + 64u < grp) part += g.group_sums[(lane + 64) * GROUP_PAD];
                 if ((uint32_t)lane < inb) part += g.block_sums[(grp << 6) + lane];
                 base = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(part), 63);
+                if (g.dense) {
+                    if ((uint32_t)lane < grp) part_g += g.group_sums_g[lane * GROUP_PAD];
+                    if ((uint32_t)lane + 64u < grp) part_g += g.group_sums_g[(lane + 64) * GROUP_PAD];
+                    if ((uint32_t)lane < inb) part_g += g.block_sums_g[(grp << 6) + lane];
+                    gbase = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(part_g), 63);
+                }
             } else {
                 base = g.block_sums[cb];
             }
             const uint32_t coff = base + (en.y & 0xFFFFu);
             const bool ok = MODE != 0 ? coff + cn <= g.cap : g.cnt->n_setup != 0u;
-            if (ok) clip_triangle_wave<VS>(g, u, ct, coff, lane, s_cxy[w], s_ckey[w], s_cv[w]);
+            if (ok) clip_triangle_wave<VS>(g, u, ct, coff, gbase + en.z, lane, s_cxy[w], s_ckey[w], s_cv[w]);
         }
     }
 }
