@@ -600,7 +600,6 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     a.rank = c->rank; a.world = c->world;
     a.rpr = (c->part_blocked && c->world > 1) ? std::max(1, (a.tiles_y + c->world - 1) / c->world) : 0;
     a.recs = c->recs; a.vary = c->vary; a.pbox = c->pbox;
-    a.gidx = c->geom_dense ? c->gidx : nullptr;
     a.tile_counts = c->tile_counts; a.tile_offsets = c->tile_offsets; a.tile_cursor = c->tile_cursor;
     const uint32_t ntiles = (uint32_t)a.tiles_x * a.tiles_y;
     int rc;

@@ -40,7 +40,9 @@ struct Counters {
     uint32_t pad0;
     unsigned long long seg_total[2]; // segmented binning: entries reserved by the current / previous draw (slots alternate per draw)
     uint32_t clip_n[2];              // clipped triangles listed by the current / previous draw's k_geom_count (slots alternate)
-    uint32_t ent_cursor[2];          // tile kernel: space handed out in the overflow arena of bins2 (same slots)
+    uint32_t ent_cursor[2];
+    const uint32_t *gidx;            // dense-owned draw: emission index of each setup slot, else null (set by k_geom_count; read by the
+                                     // resolve like tri_base -- a kernel argument would cost the tile kernel its sixth wave per SIMD)          // tile kernel: space handed out in the overflow arena of bins2 (same slots)
     unsigned long long dbg[12]; // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py)
 };
 
@@ -99,7 +101,6 @@ struct RasterArgs {
     const RasterRec *recs;
     const float *vary;
     const uint4 *pbox;                // see GeomArgs::pbox
-    const uint32_t *gidx;             // dense-owned draws: emission index of each setup slot (else null: the slot index)
     uint32_t *tile_counts;            // [ntiles]
     uint32_t *tile_offsets;           // [ntiles+1]
     uint32_t *tile_cursor;            // [ntiles]

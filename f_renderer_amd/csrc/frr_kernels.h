@@ -119,7 +119,10 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_count(GeomArgs g, DevUnifor
         __syncthreads();
         if (listed) g.clip_list[s_cbase + crank] = make_uint4(t, off_local | (n << 16), goff_local, 0u);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) g.cnt->clip_n[g.cslot ^ 1] = 0u; // the previous draw's list, for the next draw
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g.cnt->clip_n[g.cslot ^ 1] = 0u; // the previous draw's list, for the next draw
+        g.cnt->gidx = g.dense ? g.gidx : nullptr;
+    }
     if (g.selfsum) {
         // two-level sums for the emit blocks: one fire-and-forget atomic per block on its group's counter
         // (64 blocks per counter, one cache line per counter); the other slot, used by the previous

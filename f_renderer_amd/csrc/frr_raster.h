@@ -87,6 +87,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
                                              const unsigned long long *s_key, const float *u8lut = nullptr)
 {
     const uint32_t tri_base = a.cnt->tri_base;
+    const uint32_t *gidx = a.cnt->gidx; // dense-owned draws: slot -> emission index
     for (int i = threadIdx.x; i < TILE_PX; i += (int)blockDim.x) {
         const int x = i & (TILE - 1), y = i >> 5;
         if (x >= c.tw || y >= c.th) continue;
@@ -105,7 +106,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
             if (dz != 0.0f && dz == dz) {
                 const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
                 a.depth[di] = dz;                                                   // :366
-                a.tri_id[di] = tri_base + (a.gidx ? a.gidx[t] : t);
+                a.tri_id[di] = tri_base + (gidx ? gidx[t] : t);
                 continue;
             }
         }
@@ -116,7 +117,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
         Frag f = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), r0, r1, r2, cx, cy);
         const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
         a.depth[di] = f.rhw;                                                    // :366
-        a.tri_id[di] = tri_base + (a.gidx ? a.gidx[t] : t);
+        a.tri_id[di] = tri_base + (gidx ? gidx[t] : t);
         if constexpr (PS != FRR_PS_DEPTH) {
             const float w = recip_exact(f.rhw != 0.0f ? f.rhw : 1.0f);          // :368 (== 1.0f / x, bit for bit)
             const float c0 = r0 * f.a * w, c1 = r1 * f.b * w, c2 = r2 * f.c * w; // :370-372
