@@ -288,7 +288,7 @@ __device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevU
 // MODE 0: block_sums were exclusive-scanned by k_scan_blocks;
 // MODE 2: every block derives its prefix from the two-level sums itself (<= 8192 blocks: cheaper than a scan launch).
 template <int VS, int MODE>
-__global__ __launch_bounds__(GEOM_BLOCK) void k_geom_emit(GeomArgs g, DevUniforms u)
+__global__ __launch_bounds__(GEOM_BLOCK, 6) void k_geom_emit(GeomArgs g, DevUniforms u)
 {
     __shared__ uint32_t s_w[4], s_wg[4];
     __shared__ uint4 s_stage[GEOM_BLOCK / 64][64 * 5];    // per wave: 64 records at an 80-byte stride (see the record stores)
