@@ -325,7 +325,7 @@ __device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uin
 // NW = waves per tile workgroup: 4 when there are enough tiles to fill the chip (8 workgroups per CU),
 // 8 or 16 when a partitioned (multi-GPU) rank owns few tiles, so that a tile's bin is shared by more waves.
 template <int K, int PS, bool COUNT, int NW>
-__global__ __launch_bounds__(NW * 64) void k_raster_span(RasterArgs a, DevUniforms u, int win_safe)
+__global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUniforms u, int win_safe)
 {
     constexpr int B = SPAN_BATCH;
     __shared__ unsigned long long s_key[TILE_PX];
