@@ -165,3 +165,46 @@ def test_three_million_triangles_take_the_large_mesh_paths(oracle):
     np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
     assert st["frag_covered"] == oc["frag_covered"] and st["tris_setup"] == oc["tris_setup"]
     r.close()
+
+
+@pytest.mark.parametrize("blocked", [False, True])
+def test_clip_heavy_textured_scene_partitioned_equals_single_gpu(blocked):
+    """BASELINE config 5 (250,000-triangle sheets, a third of them through or past the frustum, textured
+    Blinn-Phong, 3840x2160) on a 4-rank partition: dense-owned geometry with many clipped triangles; the
+    stitched colour, depth and id images must equal the single-context render."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    Wc, Hc, G = 3840, 2160, 4
+    mesh = scenes.layered_sheets()
+    tex = scenes.checker_texture(1024, 32)
+    eye, at, up, fovy, aspect, zn, zf = scenes.demo_camera(Wc, Hc)
+    kw = dict(view=fr.set_look_at(eye, at, up), proj=fr.set_perspective(fovy, aspect, zn, zf), view_pos=eye, texture_slot=0)
+
+    def render(rank=None):
+        r = fr.Renderer(Wc, Hc)
+        if rank is not None:
+            r.set_partition(rank, G, blocked=blocked)
+        r.set_texture(0, tex)
+        r.set_uniforms(**kw)
+        r.clear()
+        r.draw(r.upload_mesh(mesh, fr.VS_PHONG), fr.PS_BLINN)
+        out = r.readback()
+        st = r.stats()
+        r.close()
+        return out, st
+
+    (c0, d0, t0), st0 = render()
+    rows = np.arange(Hc) // 32
+    k = -(-((Hc + 31) // 32) // G)
+    acc_c, acc_d, acc_t = np.zeros_like(c0), np.zeros_like(d0), np.zeros_like(t0)
+    for rank in range(G):
+        (c, d, t), st = render(rank)
+        assert st["tris_setup"] == st0["tris_setup"]
+        own_rows = (rows // k) == rank if blocked else (rows % G) == rank
+        own = np.repeat(own_rows, Wc)
+        acc_d[own] = d[own]
+        acc_t[own] = t[own]
+        acc_c[own_rows] = c[own_rows]
+    np.testing.assert_array_equal(acc_t, t0)
+    np.testing.assert_array_equal(acc_d.view(np.uint32), d0.view(np.uint32))
+    np.testing.assert_array_equal(acc_c, c0)
