@@ -242,3 +242,42 @@ class Frame:
         if keep_setup:
             return setup[: int(self.counters.tris_setup) - before].copy()
         return None
+
+
+def draw_banded(width, height, vs_inputs, vs_id, ps_id, uniforms, rgba=(30, 30, 30, 255), depth=0.0, threads=None):
+    """One frame with the row range split over `threads` host threads -- the reference's own sub-window
+    feature (renderer.rs:270-271): every thread runs geometry + rasterization of ALL triangles into its band
+    (window (0, W, y0, y1), band-local depth/colour buffers; ctypes releases the GIL).  Best-effort all-core CPU
+    figure for bench.py; returns (color, depth, tri_id, covered_fragments, seconds)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    vin = np.ascontiguousarray(vs_inputs, np.float32)
+    ntris = vin.size // (3 * vs_input_floats(vs_id))
+    threads = max(1, min(threads or (os.cpu_count() or 1), height))
+    edges = [height * i // threads for i in range(threads + 1)]
+    color = np.zeros((height, width, 4), np.uint8)
+    dep = np.zeros(height * width, np.float32)
+    tid = np.full(height * width, 0xFFFFFFFF, np.uint32)
+    counters = [Counters() for _ in range(threads)]
+    L = lib()
+
+    def band(i):
+        y0, y1 = edges[i], edges[i + 1]
+        if y1 <= y0:
+            return
+        c = color[y0:y1]                                      # contiguous row slices of the full images
+        d = dep[y0 * width:y1 * width]
+        t = tid[y0 * width:y1 * width]
+        fb = Framebuffer(width, y1 - y0, c.ctypes.data)
+        L.o_fb_fill(C.byref(fb), np.asarray(rgba, np.uint8).ctypes.data_as(C.POINTER(C.c_uint8)))
+        L.o_depth_fill(_f32p(d), d.size, np.float32(depth))
+        rc = L.o_draw(width, height, 0, width, y0, y1, _f32p(vin.reshape(-1)), ntris, vs_id, ps_id, C.byref(uniforms),
+                      C.byref(fb), _f32p(d), d.size, t.ctypes.data_as(C.POINTER(C.c_uint32)), 0, None, 0, C.byref(counters[i]))
+        if rc:
+            raise RuntimeError("oracle: the reference would have panicked (bounds / clamp)")
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(band, range(threads)))
+    secs = time.perf_counter() - t0
+    return color, dep, tid, sum(int(c.frag_covered) for c in counters), secs

@@ -153,3 +153,21 @@ def test_window_invariance_full_vs_windows(oracle):
             part.rasterization((0, W), (y0, y1), setup[i], oracle.PS_DEPTH, 0, u, tri_id=i)
         pd = part.depth.reshape(H, W)[: y1 - y0]
         np.testing.assert_array_equal(pd.view(np.uint32), fd[y0:y1].view(np.uint32))
+
+
+def test_banded_multithread_frame_equals_the_single_thread_frame(oracle):
+    """oracle.cref.draw_banded (bench.py's all-core CPU figure) splits the rows over threads through the
+    reference's sub-window argument; the stitched frame is the single-thread frame."""
+    from f_renderer_amd import scenes
+    W, H = 200, 150
+    tris = scenes.random_clip_triangles(3000, W, H, seed=4, spread=1.2)
+    u = oracle.make_uniforms()
+    f = oracle.Frame(W, H)
+    f.clear((1, 2, 3, 4), 0.0)
+    f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, u)
+    for threads in (1, 3, 8):
+        c, d, t, cov, _ = oracle.draw_banded(W, H, tris, oracle.VS_CLIP, oracle.PS_DEPTH, u, (1, 2, 3, 4), 0.0, threads=threads)
+        np.testing.assert_array_equal(t, f.tri_id)
+        np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+        np.testing.assert_array_equal(c, f.color)
+        assert cov == f.counters.frag_covered
