@@ -128,8 +128,9 @@ def main():
         # rows are padded to a whole number of tile rows per rank so owned bands are one strided view
         from f_renderer_amd.multigpu import BlockGather, band_layout
         _, _, HP = band_layout(H, world)
-        # two target sets: frame i renders into set i % 2 while the gather of frame i-1 (other set) is in flight
-        nsets = 2 if dist is not None else 1
+        # three target sets: frame i renders into set i % 3 while the gathers of frames i-1 and i-2 may still be in flight;
+        # before a set is reused the HOST checks that its gather (three frames back) has completed
+        nsets = 3 if dist is not None else 1
         color = [torch.zeros((HP, W), dtype=torch.int32, device="cuda") for _ in range(nsets)]
         depth = [torch.zeros((HP, W), dtype=torch.float32, device="cuda") for _ in range(nsets)]
         tri_id = [torch.full((HP, W), -1, dtype=torch.int32, device="cuda") for _ in range(nsets)]
@@ -157,7 +158,7 @@ def main():
             frame_no += 1
             if gathers is not None:
                 if inflight[s] is not None:            # the gather that last read this target set must be done
-                    final = gathers[s].finish(inflight[s])
+                    final = gathers[s].finish(inflight[s]) if args.sync_gather else gathers[s].finish_host(inflight[s])
                 r.bind_targets(color[s].data_ptr(), depth[s].data_ptr(), tri_id[s].data_ptr())
             r.clear((30, 30, 30, 255), 0.0)
             r.draw(mesh, fr.PS_DEPTH)

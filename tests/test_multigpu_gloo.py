@@ -52,6 +52,8 @@ def _worker(rank, world, port, H, W, full_np, out_path):
         local_b[y0:y1c] = full[y0:y1c]
     bg = BlockGather(H, W, torch.float32, "cpu", rank, world)
     final_b = bg.finish(bg.start(local_b))
+    final_b2 = bg.finish_host(bg.start(local_b))              # bench.py's host-polled completion
+    assert (final_b2 is None) == (rank != 0)
     if rank == 0:
         assert torch.equal(finals[0][:H], final[:H]) and torch.equal(finals[1][:H], final[:H] * 2.0)
         assert torch.equal(final_b[:H], final[:H])
