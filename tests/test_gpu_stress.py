@@ -62,3 +62,53 @@ def test_random_frame_and_partition(oracle, W, H, n, spread, wj, seed):
         np.testing.assert_array_equal(acc_t, t)
         np.testing.assert_array_equal(acc_d.view(np.uint32), d.view(np.uint32))
         assert cov == st["frag_covered"]
+
+
+WINDOWS = [
+    # W, H, (x0, x1), (y0, y1), ranks, blocked, seed     (x0 = 0 whenever y0 > 0 spans several rows: the reference's
+    (300, 200, (0, 300), (0, 200), 3, True, 1),        #  depth stride x1 is only self-consistent then)
+    (300, 200, (0, 260), (17, 190), 2, False, 2),
+    (300, 200, (0, 300), (40, 140), 4, True, 3),
+    (256, 256, (0, 200), (0, 256), 2, True, 4),
+    (640, 200, (0, 640), (5, 133), 5, False, 5),
+]
+
+
+@pytest.mark.parametrize("W,H,wr,hr,G,blocked,seed", WINDOWS)
+def test_coloured_sub_window_on_a_partition(oracle, W, H, wr, hr, G, blocked, seed):
+    """Interpolated vertex colours (K = 3) in a sub-window (the clear is settled by k_clear, not fused), on a
+    G-rank partition whose tile rows are window-local: every pixel is owned by exactly one rank and the union
+    is the oracle's frame (ids, depth, RGBA8)."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    n = 5000
+    clip = scenes.random_clip_triangles(n, W, H, seed=50 + seed, spread=1.15, w_jitter=0.3)
+    col = scenes.splitmix_u01(7 + seed, n * 9).reshape(n, 3, 3).astype(np.float32)
+    tris = np.concatenate([clip, col], axis=2)
+    f = oracle.Frame(W, H)
+    f.clear((5, 6, 7, 8), 0.0)
+    f.draw(tris, oracle.VS_CLIP_COLOR, oracle.PS_COLOR, oracle.make_uniforms(), window=(wr[0], wr[1], hr[0], hr[1]))
+    if f.counters.frag_nan:
+        pytest.skip("NaN rhw")
+    acc_t = np.full(W * H, 0xFFFFFFFF, np.uint32)
+    acc_c = np.zeros((H, W, 4), np.uint8)
+    acc_c[:] = (5, 6, 7, 8)
+    acc_d = np.zeros(W * H, np.float32)
+    for rank in range(G):
+        r = fr.Renderer(W, H)
+        r.set_partition(rank, G, blocked=blocked)
+        r.clear((5, 6, 7, 8), 0.0)
+        r.draw(r.upload_mesh(tris, fr.VS_CLIP_COLOR), fr.PS_COLOR, wr, hr)
+        c, d, t = r.readback()
+        drawn = t != 0xFFFFFFFF
+        assert not (drawn & (acc_t != 0xFFFFFFFF)).any()
+        acc_t[drawn] = t[drawn]
+        acc_d[drawn] = d[drawn]
+        # colour lives at (cx - x0, cy - y0) with the framebuffer's stride, depth/id at (cy - y0) * x1 + (cx - x0):
+        # compare colour through the oracle's own image, pixel by pixel where this rank changed it
+        changed = (c != np.array((5, 6, 7, 8), np.uint8)).any(axis=2)
+        acc_c[changed] = c[changed]
+        r.close()
+    np.testing.assert_array_equal(acc_t, f.tri_id)
+    np.testing.assert_array_equal(acc_d.view(np.uint32), f.depth.view(np.uint32))
+    np.testing.assert_array_equal(acc_c, f.color)
