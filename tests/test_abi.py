@@ -89,3 +89,16 @@ def test_framebuffer_host_surface():
     assert fb.get_data()[(2 * 5 + 1) * 4:(2 * 5 + 1) * 4 + 4].tolist() == [1, 2, 3, 4]   # offset (y*w+x)*4
     fb.clear()
     assert not fb.get_data().any()
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/frr.h is the drop-in boundary: it must compile as C (no C++, no torch/HIP types) on its own."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "frr.h"\nint use(frr_ctx *c) { frr_stats s; return frr_get_stats(c, &s) + frr_abi_version(); }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
