@@ -108,8 +108,14 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
     dist = None
+    saved_stdout_fd = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
+        # RCCL prints a version banner on file descriptor 1 when its communicator is created; this program's
+        # stdout is ONE JSON line, so everything else written to fd 1 until then goes to stderr
+        sys.stdout.flush()
+        saved_stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -221,6 +227,10 @@ def main():
     elapsed = float(t.item())
     frag_covered = int(cov.item())  # covered fragments of one frame over all ranks' tiles
 
+    if saved_stdout_fd is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout_fd, 1)
+        os.close(saved_stdout_fd)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         mtri = ntris / (ms_per_step * 1e-3) / 1e6
