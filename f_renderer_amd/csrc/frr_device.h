@@ -354,8 +354,12 @@ __device__ __forceinline__ void sample_2d(const DevUniforms &u, float uu, float 
     const uint8_t *p21 = reinterpret_cast<const uint8_t *>(&q21), *p22 = reinterpret_cast<const uint8_t *>(&q22);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float t11 = u8lut ? u8lut[p11[k]] : (float)p11[k] / 255.0f, t12 = u8lut ? u8lut[p12[k]] : (float)p12[k] / 255.0f;
-        const float t21 = u8lut ? u8lut[p21[k]] : (float)p21[k] / 255.0f, t22 = u8lut ? u8lut[p22[k]] : (float)p22[k] / 255.0f;
+        float t11, t12, t21, t22;
+        if (u8lut) { // wave-uniform: one branch, not sixteen selects that would evaluate the divisions anyway
+            t11 = u8lut[p11[k]]; t12 = u8lut[p12[k]]; t21 = u8lut[p21[k]]; t22 = u8lut[p22[k]];
+        } else {
+            t11 = (float)p11[k] / 255.0f; t12 = (float)p12[k] / 255.0f; t21 = (float)p21[k] / 255.0f; t22 = (float)p22[k] / 255.0f;
+        }
         float c11 = t11 * oma * omb;
         float c12 = t12 * oma * b;
         float c21 = t21 * a * omb;
