@@ -77,6 +77,18 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_debug(out=None, defines=("FRR_DEBUG_COUNTERS",), verbose=False):
+    """Dev builds (tools/): the same sources with extra -D switches, e.g. the funnel/phase counters of
+    tools/debug_counters.py.  Never loaded unless FRR_LIB points at it."""
+    out = out or os.path.join(_ROOT, "tools", "libfrr_dbg.so")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-D" + d for d in defines] + ["-o", out, _SRC[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/frr.h declares

@@ -50,7 +50,8 @@ struct frr_ctx {
     uint32_t *gidx = nullptr; size_t gidx_cap = 0;                 // dense-owned draws: emission index of each setup slot
     uint2 *fast_list = nullptr; size_t fast_list_cap = 0;         // dense-owned draws: per count block, its owned unclipped triangles
     uint32_t *fast_count = nullptr; size_t fast_count_cap = 0;
-    bool geom_dense = false;   // the latest frr_geometry/frr_draw was dense-owned
+    struct GeomFilter { bool active; int32_t y0, y1; int rank, world; bool blocked; };
+    GeomFilter geom_filter = {false, 0, 0, 0, 1, false}; // tile-row ownership filter the latest setup list was built with (frr_draw on a partitioned ctx)
     bool geom_no_dense = false; // FRR_GEOM=nodense: partitioned draws keep a slot for every triangle (tests)
     int geom_slot = 0;         // group_sums slot of the latest draw (alternates)
     uint4 *clip_list = nullptr; size_t clip_list_cap = 0;     // clipped triangles of the current draw (k_geom_count -> k_geom_emit)
@@ -88,8 +89,12 @@ struct frr_ctx {
     uint64_t geom_ntris = 0;
     int rank = 0, world = 1;
     bool count_frags = true;   // exact covered-fragment statistic (disables whole-triangle early-z)
-    int raster_nw = 0;         // FRR_RASTER_NW: force 4 / 8 / 16 waves per tile workgroup (dev)
+    int raster_nw = 0;         // FRR_RASTER_NW: force 3 / 4 / 6 / 8 / 16 waves per tile workgroup (dev)
+    int raster_occ = 0;        // FRR_RASTER_OCC: force the 6- or 8-waves-per-SIMD build of the tile kernel (dev)
     bool raster_sweep = false; // FRR_RASTER=sweep: brute-force tile kernel instead of the span kernel
+#ifdef FRR_DEBUG_COUNTERS
+    unsigned long long *dbg_tiles = nullptr; // FRR_DEBUG_TILES: per-tile timeline of the latest tile kernel
+#endif
     hipEvent_t ev[16] = {};
     bool ev_set[16] = {};
     uint32_t prof_mask = 0;   // bit per KernelId
@@ -218,7 +223,29 @@ template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks
     }
 }
 
-template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uint32_t grid)
+// Shape of the tile kernel's workgroups for `grid` tiles: NW waves per tile and the waves per SIMD its registers are
+// budgeted for.  Candidates (NW, workgroups resident per CU): (3, 8) (4, 8) (4, 6) (6, 4) (8, 3) (16, 1); a tile takes
+// about 1/NW of the time with NW waves, so the cost of a launch is rounds(grid / resident) / NW and the shape that
+// minimises it wins (ties: fewer, wider workgroups -- shorter chains).  256 CUs.
+struct SpanShape { int nw, occ; };
+SpanShape span_shape(const frr_ctx *c, uint32_t grid)
+{
+    struct Cand { int nw, occ, per_cu; };
+    static const Cand cands[] = {{16, 4, 1}, {8, 6, 3}, {6, 6, 4}, {4, 8, 8}, {4, 6, 6}, {3, 6, 8}};
+    SpanShape best = {4, 6};
+    double best_cost = 1e30;
+    for (const Cand &k : cands) {
+        if (c->raster_nw && k.nw != c->raster_nw) continue;
+        if (c->raster_occ && k.occ != c->raster_occ) continue;
+        const uint32_t resident = 256u * (uint32_t)k.per_cu;
+        const double rounds = (double)((grid + resident - 1) / resident);
+        const double cost = rounds / (double)k.nw;
+        if (cost < best_cost - 1e-12) { best_cost = cost; best = {k.nw, k.occ}; }
+    }
+    return best;
+}
+
+template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uint32_t grid, const SpanShape sh)
 {
     ProfScope p(c, KID_RASTER);
     if (c->raster_sweep) {
@@ -226,20 +253,18 @@ template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uin
     } else {
         // the span algebra needs every coordinate it touches within +-SPAN_SAFE (no i32 wrap)
         const int win_safe = a.x0 >= -SPAN_SAFE && a.y0 >= -SPAN_SAFE && a.x1 <= SPAN_SAFE && a.y1 <= SPAN_SAFE;
-        // waves per tile: the kernel's registers allow 24 waves per CU, so the widest workgroup that still
-        // places every tile in ONE round over the 256 CUs (a partitioned rank or a small window has few
-        // tiles; more waves per tile shorten its chain)
-        int nw = grid <= 256 ? 16 : (grid <= 768 ? 8 : 4);
-        if (c->raster_nw) nw = c->raster_nw;
-        auto go = [&](auto count_tag, auto nw_tag) {
+        auto go = [&](auto count_tag, auto nw_tag, auto occ_tag) {
             constexpr bool CNT = decltype(count_tag)::value;
-            constexpr int NWV = decltype(nw_tag)::value;
-            hipLaunchKernelGGL((k_raster_span<K, PS, CNT, NWV>), dim3(grid), dim3(NWV * 64), 0, c->stream, a, c->duni, win_safe);
+            constexpr int NWV = decltype(nw_tag)::value, OCCV = decltype(occ_tag)::value;
+            hipLaunchKernelGGL((k_raster_span<K, PS, CNT, NWV, OCCV>), dim3(grid), dim3(NWV * 64), 0, c->stream, a, c->duni, win_safe);
         };
         auto go_nw = [&](auto count_tag) {
-            if (nw == 4) go(count_tag, std::integral_constant<int, 4>{});
-            else if (nw == 8) go(count_tag, std::integral_constant<int, 8>{});
-            else go(count_tag, std::integral_constant<int, 16>{});
+            if (sh.nw == 3) go(count_tag, std::integral_constant<int, 3>{}, std::integral_constant<int, 6>{});
+            else if (sh.nw == 4 && sh.occ == 8) go(count_tag, std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
+            else if (sh.nw == 4) go(count_tag, std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
+            else if (sh.nw == 6) go(count_tag, std::integral_constant<int, 6>{}, std::integral_constant<int, 6>{});
+            else if (sh.nw == 8) go(count_tag, std::integral_constant<int, 8>{}, std::integral_constant<int, 6>{});
+            else go(count_tag, std::integral_constant<int, 16>{}, std::integral_constant<int, 4>{});
         };
         if (c->count_frags) go_nw(std::true_type{}); else go_nw(std::false_type{});
     }
@@ -288,7 +313,8 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     frr_ctx *c = new frr_ctx();
     c->device = device; c->W = width; c->H = height;
     { const char *e = getenv("FRR_RASTER"); c->raster_sweep = e && strcmp(e, "sweep") == 0; }
-    { const char *e = getenv("FRR_RASTER_NW"); const int v = e ? atoi(e) : 0; c->raster_nw = (v == 4 || v == 8 || v == 16) ? v : 0; }
+    { const char *e = getenv("FRR_RASTER_NW"); const int v = e ? atoi(e) : 0; c->raster_nw = (v == 3 || v == 4 || v == 6 || v == 8 || v == 16) ? v : 0; }
+    { const char *e = getenv("FRR_RASTER_OCC"); const int v = e ? atoi(e) : 0; c->raster_occ = (v == 4 || v == 6 || v == 8) ? v : 0; }
     { const char *e = getenv("FRR_GEOM"); c->geom_force_scan = e && strcmp(e, "scan") == 0; c->geom_no_dense = e && strcmp(e, "nodense") == 0; }
     { const char *e = getenv("FRR_BIN_G"); c->bin_g = e ? atoi(e) : 0; }
     { const char *e = getenv("FRR_CLEAR"); c->clear_eager = e && strcmp(e, "eager") == 0; }
@@ -335,6 +361,9 @@ void frr_destroy(frr_ctx *c)
     void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->group_sums, c->block_sums_g, c->gidx, c->fast_list, c->fast_count, c->clip_list, c->recs, c->vary, c->pbox,
                     c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bins2, c->bin_matrix};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+#ifdef FRR_DEBUG_COUNTERS
+    if (c->dbg_tiles) (void)hipFree(c->dbg_tiles);
+#endif
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -518,18 +547,19 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
     g.cap = (uint32_t)std::min<size_t>(c->setup_cap, K > 0 ? c->vary_cap / (3 * (size_t)K) : c->setup_cap);
     g.selfsum = 0;
-    g.reset_frame = c->counters_pending ? 1 : 0;
-    c->counters_pending = false;
+    g.reset_frame = c->counters_pending ? 1 : 0; // (committed with the launch, below)
     constexpr size_t kGroupSlot = (size_t)128 * GROUP_PAD; // 4 slots: {owned, all triangles} x {this draw, previous draw}
     if (!c->group_sums) {
         if ((rc = ensure(c, c->group_sums, c->group_sums_cap, 4 * kGroupSlot)) != FRR_OK) return rc;
         HIP_TRY(c, hipMemsetAsync(c->group_sums, 0, 4 * kGroupSlot * sizeof(uint32_t), c->stream));
     }
-    c->geom_slot ^= 1;
-    g.group_sums = c->group_sums + (size_t)c->geom_slot * kGroupSlot;
-    g.group_zero = c->group_sums + (size_t)(c->geom_slot ^ 1) * kGroupSlot;
-    g.group_sums_g = c->group_sums + (size_t)(2 + c->geom_slot) * kGroupSlot;
-    g.group_zero_g = c->group_sums + (size_t)(2 + (c->geom_slot ^ 1)) * kGroupSlot;
+    // the per-draw slot (group sums, clipped-triangle counter) alternates; it is committed only when the draw's
+    // kernels are launched (a failed allocation below must not leave a slot toggled that nobody zeroed)
+    const int slot = c->geom_slot ^ 1;
+    g.group_sums = c->group_sums + (size_t)slot * kGroupSlot;
+    g.group_zero = c->group_sums + (size_t)(slot ^ 1) * kGroupSlot;
+    g.group_sums_g = c->group_sums + (size_t)(2 + slot) * kGroupSlot;
+    g.group_zero_g = c->group_sums + (size_t)(2 + (slot ^ 1)) * kGroupSlot;
     // dense-owned draw: partitioned ctx + frr_draw (the window is known) + a mesh the emit blocks can offset themselves
     g.dense = (filter && c->world > 1 && nblocks <= 8192 && !c->geom_force_scan && !c->geom_no_dense) ? 1 : 0;
     g.block_sums_g = nullptr; g.gidx = nullptr; g.fast_list = nullptr; g.fast_count = nullptr;
@@ -540,17 +570,20 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
         if ((rc = ensure(c, c->fast_count, c->fast_count_cap, (size_t)nblocks)) != FRR_OK) return rc;
         g.block_sums_g = c->block_sums_g; g.gidx = c->gidx; g.fast_list = c->fast_list; g.fast_count = c->fast_count;
     }
-    c->geom_dense = g.dense != 0;
     g.part_rank = c->rank; g.part_world = filter ? c->world : 1; g.part_y0 = fy0; g.part_y1 = fy1;
     g.part_rpr = 0;
     if (filter && c->part_blocked) {
         const int tiles_y = (int)(((int64_t)fy1 - fy0 + TILE - 1) / TILE);
         g.part_rpr = std::max(1, (tiles_y + c->world - 1) / c->world);
     }
-    g.block_sums = c->block_sums; g.clip_list = c->clip_list; g.cslot = c->geom_slot;
+    // what the setup list about to be built was filtered by (frr_raster / frr_readback_setup check it)
+    c->geom_filter = frr_ctx::GeomFilter{filter, fy0, fy1, c->rank, c->world, c->part_blocked};
+    c->geom_slot = slot;
+    c->counters_pending = false;
+    g.block_sums = c->block_sums; g.clip_list = c->clip_list; g.cslot = slot;
     g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;
     if (nt == 0) {
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, 0u, g.cap, 0u, g.cnt, g.reset_frame);
+        hipLaunchKernelGGL(k_geom_empty, dim3(1), dim3(128), 0, c->stream, g);
     } else {
         switch (m.vs) {
         case FRR_VS_CLIP: launch_geometry<FRR_VS_CLIP>(c, g, nblocks); break;
@@ -584,6 +617,14 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     if ((ps_id == FRR_PS_COLOR && K != 3) || ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && K != 8) || ps_id < 0 || ps_id > FRR_PS_BLINN)
         return fail(c, FRR_ERR_INVALID, "pixel shader does not match the vertex shader's varyings");
     if ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && !c->duni.tex) return fail(c, FRR_ERR_INVALID, "no texture bound to uniforms.texture_slot");
+    {
+        // frr_draw on a partitioned ctx keeps only the triangles that touch the rank's tile rows of ITS window; that
+        // list serves no other window or partition (the reference may reuse one geometry for several ranges,
+        // renderer.rs:269-271: use frr_geometry for that, it never filters)
+        const frr_ctx::GeomFilter &gf = c->geom_filter;
+        if (gf.active && (gf.y0 != y0 || gf.y1 != y1 || gf.rank != c->rank || gf.world != c->world || gf.blocked != c->part_blocked))
+            return fail(c, FRR_ERR_INVALID, "the setup list was filtered by frr_draw for another window/partition; re-run frr_geometry (unfiltered) before frr_raster");
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     if (ww == 0 || wh == 0 || c->geom_ntris == 0) return FRR_OK;
     bool fuse = false;
@@ -612,12 +653,24 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     a.bins2 = c->bins2;
     a.bins = c->bins; a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xFFFFFFFFu);
     a.color = c->color; a.depth = c->depth; a.tri_id = c->tri_id; a.cnt = c->cnt;
+#ifdef FRR_DEBUG_COUNTERS
+    if (!c->dbg_tiles && getenv("FRR_DEBUG_TILES")) {
+        if (hipMalloc((void **)&c->dbg_tiles, (size_t)c->max_tiles * 64) != hipSuccess) c->dbg_tiles = nullptr;
+    }
+    if (c->dbg_tiles) (void)hipMemsetAsync(c->dbg_tiles, 0, (size_t)c->max_tiles * 64, c->stream);
+    a.dbg_tiles = c->dbg_tiles;
+#endif
     a.seg = nullptr; a.nseg = 0; a.slot = 0;
+    const int owned_rows = a.rpr > 0 ? std::max(0, std::min(a.tiles_y, (a.rank + 1) * a.rpr) - a.rank * a.rpr)
+                                     : (a.tiles_y > a.rank ? (a.tiles_y - a.rank + a.world - 1) / a.world : 0);
+    const uint32_t grid = (uint32_t)a.tiles_x * owned_rows;
+    const SpanShape sh = span_shape(c, grid);
     if (ntiles <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep) {
         // segmented LDS multi-split (one launch, no per-entry global atomics): G chunk workgroups, ~3K triangles each
         // (small meshes: one triangle per thread, so that the launch is not three workgroups doing all the work)
         uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + BIN_WG - 1) / BIN_WG, 1), BIN_MAX_G);
         if (c->bin_g > 0) G = (uint32_t)std::min(c->bin_g, BIN_MAX_G);
+        G = std::min<uint32_t>(G, (uint32_t)sh.nw * 64u); // the tile kernel reads one segment per thread
         if ((rc = ensure(c, c->bin_matrix, c->bin_matrix_cap, (size_t)BIN_MAX_G * ((size_t)c->max_tiles + 1))) != FRR_OK) return rc;
         // dynamic LDS: tile counters + as many staged 16-B records as fit (a chunk emits ~1.8 records per triangle)
         constexpr size_t kLdsBudget = 160 * 1024 - 1024; // the kernel's static LDS is < 1 KB
@@ -646,16 +699,13 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         { ProfScope p(c, KID_TILE_SCAN); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, a, ntiles); }
         { ProfScope p(c, KID_BIN_FILL); hipLaunchKernelGGL(k_bin<true>, dim3(bin_grid), dim3(256), 0, c->stream, a); }
     }
-    const int owned_rows = a.rpr > 0 ? std::max(0, std::min(a.tiles_y, (a.rank + 1) * a.rpr) - a.rank * a.rpr)
-                                     : (a.tiles_y > a.rank ? (a.tiles_y - a.rank + a.world - 1) / a.world : 0);
-    const uint32_t grid = (uint32_t)a.tiles_x * owned_rows;
     if (grid) {
         switch (ps_id) {
-        case FRR_PS_DEPTH: launch_raster<0, FRR_PS_DEPTH>(c, a, grid); break;
-        case FRR_PS_FLAT: launch_raster<0, FRR_PS_FLAT>(c, a, grid); break;
-        case FRR_PS_COLOR: launch_raster<3, FRR_PS_COLOR>(c, a, grid); break;
-        case FRR_PS_PHONG: launch_raster<8, FRR_PS_PHONG>(c, a, grid); break;
-        case FRR_PS_BLINN: launch_raster<8, FRR_PS_BLINN>(c, a, grid); break;
+        case FRR_PS_DEPTH: launch_raster<0, FRR_PS_DEPTH>(c, a, grid, sh); break;
+        case FRR_PS_FLAT: launch_raster<0, FRR_PS_FLAT>(c, a, grid, sh); break;
+        case FRR_PS_COLOR: launch_raster<3, FRR_PS_COLOR>(c, a, grid, sh); break;
+        case FRR_PS_PHONG: launch_raster<8, FRR_PS_PHONG>(c, a, grid, sh); break;
+        case FRR_PS_BLINN: launch_raster<8, FRR_PS_BLINN>(c, a, grid, sh); break;
         }
     }
     HIP_TRY(c, hipGetLastError());
@@ -700,6 +750,8 @@ int frr_readback(frr_ctx *c, uint8_t *rgba, float *depth, uint32_t *tri_id)
 int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uint64_t *ntris)
 {
     if (!c || !ntris || c->geom_vs < 0) return fail(c, FRR_ERR_INVALID, "no geometry to read back");
+    if (c->geom_filter.active)
+        return fail(c, FRR_ERR_INVALID, "the setup list of a partitioned frr_draw holds only this rank's triangles; use frr_geometry to read back the full Vec<[Vertex;3]>");
     { int rcs = settle(c); if (rcs != FRR_OK) return rcs; }
     Counters h;
     int rc = check_frame_counters(c, &h);
@@ -744,7 +796,11 @@ int frr_get_stats(frr_ctx *c, frr_stats *out)
     out->overflow = h.overflow;
     if (getenv("FRR_DEBUG_PRINT")) {
         fprintf(stderr, "frr dbg:");
-        for (int k = 0; k < 12; ++k) fprintf(stderr, " %llu", h.dbg[k]);
+        for (int k = 0; k < 24; ++k) {
+            unsigned long long v = 0;
+            for (int j = 0; j < DBG_COPIES; ++j) v += h.dbg[j][k];
+            fprintf(stderr, " %llu", v);
+        }
         fprintf(stderr, "\n");
     }
     return FRR_OK;
@@ -900,6 +956,18 @@ int frr_debug_rcp_check(frr_ctx *c, uint32_t lo_bits, uint32_t hi_bits, uint64_t
     *first_bad = (uint32_t)out[1];
     return FRR_OK;
 }
+
+#ifdef FRR_DEBUG_COUNTERS
+// dev builds only (not part of include/frr.h): the per-tile timeline of the latest tile kernel, [max_tiles][8] u64
+int frr_debug_tiles(frr_ctx *c, unsigned long long *out, uint32_t *ntiles)
+{
+    if (!c || !out || !ntiles || !c->dbg_tiles) return FRR_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->dbg_tiles, (size_t)c->max_tiles * 64, hipMemcpyDeviceToHost));
+    *ntiles = c->max_tiles;
+    return FRR_OK;
+}
+#endif
 
 int frr_debug_scan64(frr_ctx *c, const uint32_t *in, uint32_t *out)
 {

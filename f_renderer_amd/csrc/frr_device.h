@@ -24,6 +24,12 @@ struct alignas(64) RasterRec {
 };
 static_assert(sizeof(RasterRec) == 64, "one cache line per triangle");
 
+#ifdef FRR_DEBUG_COUNTERS
+constexpr int DBG_COPIES = 256;
+#else
+constexpr int DBG_COPIES = 1;
+#endif
+
 struct Counters {
     uint32_t n_setup;       // setup triangles of the current draw
     uint32_t n_emit;        // triangles the current draw emits in the reference's numbering (== n_setup unless the draw is dense-owned)
@@ -43,7 +49,10 @@ struct Counters {
     uint32_t ent_cursor[2];
     const uint32_t *gidx;            // dense-owned draw: emission index of each setup slot, else null (set by k_geom_count; read by the
                                      // resolve like tri_base -- a kernel argument would cost the tile kernel its sixth wave per SIMD)          // tile kernel: space handed out in the overflow arena of bins2 (same slots)
-    unsigned long long dbg[12]; // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py)
+    // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py): funnel counters and per-phase wave cycles of the tile
+    // kernel, in DBG_COPIES copies (workgroup b adds to copy b % DBG_COPIES: thousands of device atomics on one cache
+    // line would serialise at ~17 ns each and distort what they measure); the host adds the copies up
+    unsigned long long dbg[DBG_COPIES][24];
 };
 
 struct DevUniforms {
@@ -118,6 +127,9 @@ struct RasterArgs {
     float *depth;
     uint32_t *tri_id;
     Counters *cnt;
+#ifdef FRR_DEBUG_COUNTERS
+    unsigned long long *dbg_tiles;    // [tiles][8] per-tile timeline of the tile kernel (tools/tile_timeline.py), or null
+#endif
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
@@ -134,7 +146,7 @@ __device__ __forceinline__ void reset_frame_counters(Counters *cnt)
     cnt->n_setup = 0; cnt->n_emit = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
     cnt->seg_total[0] = cnt->seg_total[1] = 0ull; cnt->ent_cursor[0] = cnt->ent_cursor[1] = 0u;
     cnt->frag_covered = 0; cnt->frag_nan = 0; cnt->tris_in = 0; cnt->bin_entries_frame = 0; cnt->draws = 0;
-    for (int k = 0; k < 12; ++k) cnt->dbg[k] = 0;
+    for (int j = 0; j < DBG_COPIES; ++j) for (int k = 0; k < 24; ++k) cnt->dbg[j][k] = 0;
 }
 
 // ---- glam pieces used by the shader table -------------------------------------

@@ -123,22 +123,41 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_count(GeomArgs g, DevUnifor
         g.cnt->clip_n[g.cslot ^ 1] = 0u; // the previous draw's list, for the next draw
         g.cnt->gidx = g.dense ? g.gidx : nullptr;
     }
+    // The other slot of the two-level sums (both sets) belongs to the previous draw and is zeroed for the next one
+    // by EVERY draw, whichever path it takes itself (self-summing or k_scan_blocks, dense-owned or not): the slots
+    // alternate per draw, so a path that skipped this would hand stale sums to the draw after it.
+    if (blockIdx.x == 0 && threadIdx.x < 128) {
+        g.group_zero[threadIdx.x * GROUP_PAD] = 0u;
+        g.group_zero_g[threadIdx.x * GROUP_PAD] = 0u;
+    }
     if (g.selfsum) {
         // two-level sums for the emit blocks: one fire-and-forget atomic per block on its group's counter
-        // (64 blocks per counter, one cache line per counter); the other slot, used by the previous
-        // draw, is zeroed for the next one
+        // (64 blocks per counter, one cache line per counter)
         if (threadIdx.x == 0 && total) atomicAdd(&g.group_sums[(blockIdx.x >> 6) * GROUP_PAD], total);
-        if (blockIdx.x == 0 && threadIdx.x < 128) g.group_zero[threadIdx.x * GROUP_PAD] = 0u;
-        if (g.dense) {
-            if (threadIdx.x == 0 && total_g) atomicAdd(&g.group_sums_g[(blockIdx.x >> 6) * GROUP_PAD], total_g);
-            if (blockIdx.x == 0 && threadIdx.x < 128) g.group_zero_g[threadIdx.x * GROUP_PAD] = 0u;
-        }
+        if (g.dense && threadIdx.x == 0 && total_g) atomicAdd(&g.group_sums_g[(blockIdx.x >> 6) * GROUP_PAD], total_g);
     }
     if (g.selfsum && blockIdx.x == 0 && threadIdx.x == 0) { // per-draw bookkeeping k_scan_blocks would do
         if (g.reset_frame) reset_frame_counters(g.cnt);
         g.cnt->tri_base += g.cnt->n_emit;                   // previous draw's triangles precede this draw's
         g.cnt->tris_in += g.ntris;
         g.cnt->draws += 1;
+    }
+}
+
+// An empty mesh launches no count kernel; this does what its block 0 would have done for the NEXT draw (zero the
+// other slot of the group sums and of the clipped-triangle counter) and then k_scan_blocks' bookkeeping.
+__global__ __launch_bounds__(128) void k_geom_empty(GeomArgs g)
+{
+    g.group_zero[threadIdx.x * GROUP_PAD] = 0u;
+    g.group_zero_g[threadIdx.x * GROUP_PAD] = 0u;
+    if (threadIdx.x == 0) {
+        Counters *cnt = g.cnt;
+        cnt->clip_n[g.cslot ^ 1] = 0u;
+        cnt->gidx = nullptr;
+        if (g.reset_frame) reset_frame_counters(cnt);
+        cnt->tri_base += cnt->n_emit;
+        cnt->need_setup = 0; cnt->n_setup = 0; cnt->n_emit = 0;
+        cnt->draws += 1;
     }
 }
 

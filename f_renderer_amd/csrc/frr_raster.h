@@ -322,34 +322,80 @@ __device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uin
     }
 }
 
-// NW = waves per tile workgroup: 4 when there are enough tiles to fill the chip (8 workgroups per CU),
-// 8 or 16 when a partitioned (multi-GPU) rank owns few tiles, so that a tile's bin is shared by more waves.
-template <int K, int PS, bool COUNT, int NW>
-__global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUniforms u, int win_safe)
+// NW = waves per tile workgroup, OCC = waves per SIMD the registers are budgeted for.  The host picks the pair that
+// wastes the fewest workgroup slots of the chip for the number of tiles at hand (launch_raster): e.g. <4, 8> keeps
+// 8 workgroups per CU resident (2048 tiles in ONE round), <6, 6> four workgroups of six waves (1024 tiles a round).
+//
+// LDS is carved by hand from one buffer so that what only the pre-pass needs (segment tables, the exchange buffer
+// of the direct path) can share its bytes with what only the main loop needs (per-wave staging and queues):
+//   [keys 8 KiB][union { main-loop staging | pre-pass tables }][hi-z][buckets][scalars][u8 table (textured only)]
+// With B = 16 staged triangles per wave and NW = 4 that is 18.0 KiB (19.0 textured): eight workgroups per CU.
+template <int NW, int B> struct SpanLds {
+    static constexpr int KEY = 0;
+    static constexpr int U0 = KEY + TILE_PX * 8;
+    // main loop, per wave
+    static constexpr int TI = U0;                       // TriI[NW][B]
+    static constexpr int FA = TI + NW * B * 32;         // float4[NW][B]  s0x s0y s1x s1y
+    static constexpr int FB = FA + NW * B * 16;         // float4[NW][B]  s2x s2y rhw0 rhw1
+    static constexpr int FC = FB + NW * B * 16;         // float2[NW][B]  rhw2, bit pattern of (triangle index + 1)
+    static constexpr int HROW = FC + NW * B * 8;        // u64[NW][B/2]   heads of (triangle -> rows): B*32 bits
+    static constexpr int HFRAG = HROW + NW * (B / 2) * 8; // u64[NW][32]  heads of (span -> fragments): 64*32 bits
+    static constexpr int Q = HFRAG + NW * 32 * 8;       // u32[NW][64]    compacted span descriptors
+    static constexpr int AQ = Q + NW * 64 * 4;          // u32[NW][64]    per wave: triangles that survived phase 1a
+    static constexpr int M_END = AQ + NW * 64 * 4;
+    // pre-pass (aliases the main-loop region; a barrier separates the two uses)
+    static constexpr int SEGPRE = U0;                   // u32[BIN_MAX_G + 1] entries of this tile before segment g
+    static constexpr int SEGSRC = SEGPRE + ((BIN_MAX_G + 1 + 3) & ~3) * 4; // u32[BIN_MAX_G] where segment g starts in a.bins
+    static constexpr int EXCH = SEGSRC + BIN_MAX_G * 4; // uint4[DIRECT_MAX] exchange buffer of the direct path
+    static constexpr int P_END = EXCH + DIRECT_MAX * 16;
+    static constexpr int U1 = M_END > P_END ? M_END : P_END;
+    static constexpr int HZ = U1;                       // u32[HZ_SIZE] hierarchical z (see hiz_rebuild)
+    static constexpr int BKT = HZ + ((HZ_SIZE + 3) & ~3) * 4; // u32[64]
+    static constexpr int SCAL = BKT + 64 * 4;           // u32[8]: next, dirty, ebase, -, w4[4]
+    static constexpr int U8 = SCAL + 8 * 4;             // float[256] (textured shaders)
+    static constexpr int bytes(bool textured) { return U8 + (textured ? 256 * 4 : 0); }
+};
+
+template <int K, int PS, bool COUNT, int NW, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevUniforms u, int win_safe)
 {
-    constexpr int B = SPAN_BATCH;
-    __shared__ unsigned long long s_key[TILE_PX];
-    __shared__ TriI s_ti[NW][B];
-    __shared__ float4 s_fa[NW][B];                  // s0x s0y s1x s1y
-    __shared__ float4 s_fb[NW][B];                  // s2x s2y rhw0 rhw1
-    __shared__ float2 s_fc[NW][B];                  // rhw2, bit pattern of (triangle index + 1)
-    __shared__ unsigned long long s_hrow[NW][B / 2]; // heads of (triangle -> rows): B*32 bits
-    __shared__ unsigned long long s_hfrag[NW][32];  // heads of (span -> fragments): 64*32 bits
-    __shared__ uint32_t s_q[NW][64];                // compacted span descriptors
-    __shared__ uint32_t s_aq[NW][64];               // per wave: triangles that survived phase 1a
-    __shared__ __attribute__((aligned(16))) uint32_t s_hz[HZ_SIZE]; // hierarchical z (see hiz_rebuild)
-    __shared__ uint32_t s_next;
-    __shared__ uint32_t s_dirty;                    // keys changed since the hierarchical z was last rebuilt
-    __shared__ uint32_t s_bkt[64];
-    __shared__ uint32_t s_segpre[BIN_MAX_G + 1];      // segmented binning: entries of this tile before segment g
-    __shared__ uint32_t s_segsrc[BIN_MAX_G];          //                     where segment g starts in a.bins
-    __shared__ uint32_t s_w4[4];
-    __shared__ uint32_t s_ebase;
+    constexpr int B = (OCC >= 8 || NW <= 3) ? 16 : SPAN_BATCH; // staged triangles per wave (LDS budget of 8 workgroups per CU)
     constexpr bool TEXTURED = PS == FRR_PS_PHONG || PS == FRR_PS_BLINN;
-    __shared__ float s_u8[TEXTURED ? 256 : 1];       // (float)i / 255.0f for the texture taps of the resolve
+    using L = SpanLds<NW, B>;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[L::bytes(TEXTURED)];
+    unsigned long long *const s_key = reinterpret_cast<unsigned long long *>(s_raw + L::KEY);
+    TriI (*const s_ti)[B] = reinterpret_cast<TriI (*)[B]>(s_raw + L::TI);
+    float4 (*const s_fa)[B] = reinterpret_cast<float4 (*)[B]>(s_raw + L::FA);
+    float4 (*const s_fb)[B] = reinterpret_cast<float4 (*)[B]>(s_raw + L::FB);
+    float2 (*const s_fc)[B] = reinterpret_cast<float2 (*)[B]>(s_raw + L::FC);
+    unsigned long long (*const s_hrow)[B / 2] = reinterpret_cast<unsigned long long (*)[B / 2]>(s_raw + L::HROW);
+    unsigned long long (*const s_hfrag)[32] = reinterpret_cast<unsigned long long (*)[32]>(s_raw + L::HFRAG);
+    uint32_t (*const s_q)[64] = reinterpret_cast<uint32_t (*)[64]>(s_raw + L::Q);
+    uint32_t (*const s_aq)[64] = reinterpret_cast<uint32_t (*)[64]>(s_raw + L::AQ);
+    uint32_t *const s_segpre = reinterpret_cast<uint32_t *>(s_raw + L::SEGPRE);
+    uint32_t *const s_segsrc = reinterpret_cast<uint32_t *>(s_raw + L::SEGSRC);
+    uint4 *const s_exch = reinterpret_cast<uint4 *>(s_raw + L::EXCH);
+    uint32_t *const s_hz = reinterpret_cast<uint32_t *>(s_raw + L::HZ);
+    uint32_t *const s_bkt = reinterpret_cast<uint32_t *>(s_raw + L::BKT);
+    uint32_t &s_next = *reinterpret_cast<uint32_t *>(s_raw + L::SCAL);
+    uint32_t &s_dirty = *reinterpret_cast<uint32_t *>(s_raw + L::SCAL + 4); // keys changed since the hierarchical z was last rebuilt
+    uint32_t &s_ebase = *reinterpret_cast<uint32_t *>(s_raw + L::SCAL + 8);
+    uint32_t *const s_w4 = reinterpret_cast<uint32_t *>(s_raw + L::SCAL + 16);
+    float *const s_u8 = reinterpret_cast<float *>(s_raw + L::U8);  // (float)i / 255.0f for the texture taps of the resolve
     if (TEXTURED) for (int i = threadIdx.x; i < 256; i += NW * 64) s_u8[i] = (float)i / 255.0f; // ordered by the barriers below
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef FRR_DEBUG_COUNTERS
+    // wave-cycles per phase (s_memtime): 0 pre-pass, 1 phase 1a, 2 hi-z rebuild, 3 phase 1b, 4 phase 2, 5 phase 3,
+    // 6 wait at the final barrier, 7 resolve
+    unsigned long long d_tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long d_rt0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz, the same counter on every XCD
+    unsigned long long d_rt1 = 0, d_rt2 = 0;
+    uint32_t d_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define FRR_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); d_t[i] += (uint32_t)(now_ - d_tlast); d_tlast = now_; } while (0)
+#else
+#define FRR_T(i) do { } while (0)
+#endif
     TileCtx c = tile_ctx(a);
     const bool segmented = a.nseg != 0;
     if (segmented) {
@@ -362,6 +408,7 @@ __global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUni
         }
         const uint32_t inc = wave_incl_scan_dpp(cn);
         if (lane == 63 && w < 4) s_w4[w] = inc;
+        if (NW < 4 && threadIdx.x == 0) s_w4[3] = 0u; // (the host keeps nseg <= NW * 64)
         __syncthreads();
         const uint32_t w0 = s_w4[0], w1 = s_w4[1], w2 = s_w4[2], w3 = s_w4[3];
         const uint32_t total = __builtin_amdgcn_readfirstlane((w0 + w1) + (w2 + w3)); // wave-uniform, and the compiler should know
@@ -370,6 +417,7 @@ __global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUni
             s_segpre[threadIdx.x] = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u) + inc - cn;
             s_segsrc[threadIdx.x] = s0;
         }
+        for (int i = threadIdx.x + NW * 64; i < BIN_MAX_G; i += NW * 64) { s_segpre[i] = total; s_segsrc[i] = 0u; } // NW < 4 only
         if (threadIdx.x == 0) {
             s_segpre[BIN_MAX_G] = total;
             // where this tile's near-first copy goes: its own fixed slot of bins2, or -- a tile hotter than
@@ -407,12 +455,12 @@ __global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUni
     // reject more.
     uint4 *__restrict__ ents = a.bins2;
     // A tile with few records (<= DIRECT_MAX, at most one per thread) never goes through bins2: the records
-    // are ordered near-first through LDS (the bucket sort below on an exchange buffer that aliases the
-    // phase-1b staging), wave w keeps the records at sorted positions w, w+NW, ... in registers (nearest in
+    // are ordered near-first through LDS (the bucket sort below on an exchange buffer that shares its bytes
+    // with the main loop's staging), wave w keeps the records at sorted positions w, w+NW, ... in registers (nearest in
     // lane 0) and culls them in DIRECT_STEPS steps, so that later steps already see the depths the
     // nearer triangles left behind.
     const uint32_t nent = c.end - c.beg;
-    const bool direct = nent <= (uint32_t)DIRECT_MAX;
+    const bool direct = nent <= (uint32_t)(DIRECT_MAX < NW * 64 ? DIRECT_MAX : NW * 64);
     uint4 dent = make_uint4(0, 0, 0, 0);
     bool dvalid = false;
     int dcount = 0, dpos = 0, dstep = 64; // lanes of this wave that hold a record; next lane to cull; lanes per step
@@ -428,7 +476,7 @@ __global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUni
             s_bkt[lane] = incl - x;
         }
         __syncthreads();
-        uint4 *exch = reinterpret_cast<uint4 *>(&s_ti[0][0]); // NW * 32 * 32 B >= 256 records
+        uint4 *const exch = s_exch;
         if (have) exch[atomicAdd(&s_bkt[bkt], 1u)] = rec;
         __syncthreads();
         const uint32_t q = (uint32_t)lane * NW + (uint32_t)w;
@@ -479,6 +527,10 @@ __global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUni
 
     int aq_n = 0;            // survivors waiting in this wave's queue (wave-uniform)
     bool input_done = false;
+    FRR_T(0);
+#ifdef FRR_DEBUG_COUNTERS
+    d_rt1 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (;;) {
         // ---- phase 1a: lane = bin entry, 64 per step.  bbox-in-tile + whole-triangle early-z on the
         // 16-byte cull records only; survivors are queued, nothing else is touched for the rest. ----
@@ -503,11 +555,13 @@ __global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUni
                 // the minima are rebuilt only if some wave has resolved fragments since the last rebuild
                 // (a stale minimum is a lower one: still conservative)
                 if (__builtin_amdgcn_readfirstlane(s_dirty) != 0u) {
+                    FRR_T(1);
                     if (lane == 0) s_dirty = 0u;
                     hiz_rebuild(s_key, s_hz, lane);
 #ifdef FRR_DEBUG_COUNTERS
                     ++d_rebuild;
 #endif
+                    FRR_T(2);
                 }
                 wave_lds_fence();
                 const bool valid = direct ? (dvalid && lane >= dlo && lane < dlo + dstep) : lane < (int)min((uint32_t)SPAN_CULL, c.end - e0);
@@ -552,6 +606,7 @@ __global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUni
                 wave_lds_fence();
             }
         }
+        FRR_T(1);
         if (aq_n == 0) { if (input_done) break; continue; }
 
         // ---- phase 1b: lane = surviving triangle.  Record gather, edge coefficients, staging ----
@@ -610,6 +665,7 @@ __global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUni
         wave_lds_fence();
 
         int jbase = 0, jcarry = 0; // heads seen in earlier row windows; rows of the open triangle already done
+        FRR_T(3);
         for (int r0 = 0; r0 < R; r0 += 64) {
             // ---- phase 2: lane = (triangle, row).  Exact covered span of that row. ----
             const unsigned long long hrow = s_hrow[w][r0 >> 6];
@@ -666,7 +722,7 @@ __global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUni
 #ifdef FRR_DEBUG_COUNTERS
             d_spans_live += __popcll(nz);
 #endif
-            if (nz == 0ull) continue;
+            if (nz == 0ull) { FRR_T(4); continue; }
             const int srank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
             const uint32_t fincl = wave_incl_scan_dpp((uint32_t)len);
             const int F = (int)__builtin_amdgcn_readlane((int)fincl, 63);
@@ -684,6 +740,7 @@ __global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUni
             d_frags += F; d_fwin += (F + 63) / 64;
 #endif
             int qbase = 0, qcarry = 0;
+            FRR_T(4);
             for (int f0 = 0; f0 < F; f0 += 64) {
                 const unsigned long long hf = s_hfrag[w][f0 >> 6];
                 const uint32_t g_lo = __builtin_amdgcn_readfirstlane((uint32_t)hf);
@@ -711,14 +768,16 @@ __global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUni
             }
             if (lane == 0) s_dirty = 1u;
             wave_lds_fence(); // s_q / s_hfrag are rewritten by the next row window
+            FRR_T(5);
         }
 
         wave_lds_fence(); // staging is rewritten by the next batch
     }
     if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
 #ifdef FRR_DEBUG_COUNTERS
+    d_rt2 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
-        unsigned long long *d = a.cnt->dbg;
+        unsigned long long *d = a.cnt->dbg[blockIdx.x % DBG_COPIES];
         atomicAdd(d + 0, (unsigned long long)d_tri); atomicAdd(d + 1, (unsigned long long)d_alive); atomicAdd(d + 2, (unsigned long long)d_rows);
         atomicAdd(d + 3, (unsigned long long)d_spans); atomicAdd(d + 4, (unsigned long long)d_spans_live); atomicAdd(d + 5, (unsigned long long)d_frags);
         atomicAdd(d + 6, (unsigned long long)d_fwin); atomicAdd(d + 7, (unsigned long long)d_rwin);
@@ -727,7 +786,26 @@ __global__ __launch_bounds__(NW * 64, 6) void k_raster_span(RasterArgs a, DevUni
 #endif
     if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
     __syncthreads();
+    FRR_T(6);
     tile_resolve<K, PS>(a, u, c, s_key, TEXTURED ? s_u8 : nullptr);
+#ifdef FRR_DEBUG_COUNTERS
+    FRR_T(7);
+    if (lane == 0) {
+        unsigned long long *d = a.cnt->dbg[blockIdx.x % DBG_COPIES];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(d + 12 + i, (unsigned long long)d_t[i]);
+        atomicAdd(d + 20, 1ull); // waves that ran the main loop
+        if (a.dbg_tiles && w == 0) {
+            // timeline of this workgroup: start / main loop / end on the 100 MHz clock, where it ran, how much it had to do
+            unsigned long long *tl = a.dbg_tiles + (size_t)blockIdx.x * 8;
+            tl[0] = d_rt0; tl[1] = d_rt1; tl[2] = d_rt2; tl[3] = __builtin_amdgcn_s_memrealtime();
+            tl[4] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); // HW_ID, XCC_ID
+            tl[5] = (unsigned long long)(c.end - c.beg) | ((unsigned long long)(uint32_t)c.tile << 32);
+            tl[6] = d_t[1] + d_t[3] + d_t[4] + d_t[5]; tl[7] = d_t[0];
+        }
+    }
+#endif
+#undef FRR_T
 }
 
 // debug: the DPP scan against a serial sum (tests)

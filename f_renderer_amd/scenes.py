@@ -163,6 +163,45 @@ def demo_camera(width, height):
     return (0.0, 1.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), math.pi * 0.25, float(width) / float(height), 0.1, 100.0
 
 
+# ---- the BASELINE.json configs as data (bench.py, tests/golden/make_frames.py, the parity tests, tools/) ------------
+
+CONFIG_NAMES = ("cfg1", "cfg2", "cfg3", "cfg3b", "cfg4", "cfg5", "headline")
+
+
+def build_config(name, reduced=False):
+    """One BASELINE.json config as plain data: dict(name, W, H, mesh [n,3,NF] f32, vs, ps (names of
+    the shader-table entries), cam (use demo_camera), tex (RGBA8 or None), flat_color).  `reduced`: the same
+    scene at 1/8 of the linear frame size with a coarser mesh -- what the CPU-only tests and the NumPy oracle
+    can afford."""
+    flat = (1.0, 0.5, 0.25, 1.0)
+    r = bool(reduced)
+    if name == "cfg1":
+        W = H = 64 if r else 512
+        return dict(name=name, W=W, H=H, mesh=single_triangle(), vs="CLIP", ps="FLAT", cam=False, tex=None, flat_color=flat)
+    if name == "cfg2":
+        W, H = (240, 135) if r else (1920, 1080)
+        return dict(name=name, W=W, H=H, mesh=torus(12, 10) if r else torus(), vs="GOURAUD", ps="COLOR", cam=True, tex=None, flat_color=flat)
+    if name in ("cfg3", "cfg3b"):
+        W, H = (240, 135) if r else (1920, 1080)
+        tex = checker_texture(64, 8) if r else checker_texture(1024, 32)
+        return dict(name=name, W=W, H=H, mesh=displaced_sphere(n=16 if r else 186), vs="PHONG", ps="PHONG" if name == "cfg3" else "BLINN",
+                    cam=True, tex=tex, flat_color=flat)
+    if name == "cfg4":
+        W = H = 512 if r else 4096
+        n = 2000 if r else 1_000_000
+        return dict(name=name, W=W, H=H, mesh=random_clip_triangles(n, W, H), vs="CLIP", ps="DEPTH", cam=False, tex=None, flat_color=flat)
+    if name == "headline":
+        W, H = (240, 135) if r else (1920, 1080)
+        n = 2000 if r else 1_000_000
+        return dict(name=name, W=W, H=H, mesh=random_clip_triangles(n, W, H), vs="CLIP", ps="DEPTH", cam=False, tex=None, flat_color=flat)
+    if name == "cfg5":
+        W, H = (480, 270) if r else (3840, 2160)
+        tex = checker_texture(64, 8) if r else checker_texture(1024, 32)
+        mesh = layered_sheets(10, 6, 5) if r else layered_sheets()
+        return dict(name=name, W=W, H=H, mesh=mesh, vs="PHONG", ps="BLINN", cam=True, tex=tex, flat_color=flat)
+    raise KeyError(name)
+
+
 CONFIGS = {
     "cfg1_single_triangle": dict(width=512, height=512),
     "cfg2_torus_gouraud": dict(width=1920, height=1080),

@@ -159,7 +159,11 @@ int frr_geometry(frr_ctx *ctx, int mesh, uint64_t *ntris_setup);
  * window is addressed locally: pixel (cx,cy) lands at colour (cx-x0, cy-y0) with row stride
  * `width` and at depth index (cy-y0)*x1 + (cx-x0) (renderer.rs:323,326,362,381). */
 int frr_raster(frr_ctx *ctx, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1);
-/* frr_geometry + frr_raster */
+/* frr_geometry + frr_raster.  On a partitioned ctx (frr_set_partition, world > 1) the setup list frr_draw builds
+ * keeps only the triangles that touch this rank's tile rows of THIS window: a later frr_raster with another
+ * window, or after the partition changed, fails with FRR_ERR_INVALID (the reference may reuse one geometry for
+ * several ranges, renderer.rs:269-271 -- call frr_geometry for that, it never filters), and so does
+ * frr_readback_setup. */
 int frr_draw(frr_ctx *ctx, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1);
 
 int frr_sync(frr_ctx *ctx);

@@ -58,3 +58,124 @@ def test_repeated_draws_per_draw_state_resets(oracle, monkeypatch, geom):
         _, d, t = r.readback()
         np.testing.assert_array_equal(t, f.tri_id)
         np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+
+
+@pytest.mark.parametrize("nw,occ", [(3, 6), (4, 6), (4, 8), (6, 6), (8, 6), (16, 4)])
+@pytest.mark.parametrize("scene", ["depth_heavy", "phong"])
+def test_tile_kernel_shapes_agree_with_oracle(oracle, monkeypatch, nw, occ, scene):
+    """Every (waves per tile, register budget) build of k_raster_span the host may pick (span_shape in
+    frr_api.hip), forced through FRR_RASTER_NW / FRR_RASTER_OCC: same bits as the oracle.  The depth scene has
+    tiles above and below the direct-path limit (256 records) and more than 192 binning chunks' worth of
+    triangles; the Phong scene runs the textured resolve (K = 8)."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    monkeypatch.setenv("FRR_RASTER_NW", str(nw))
+    monkeypatch.setenv("FRR_RASTER_OCC", str(occ))
+    if scene == "depth_heavy":
+        W, H, n = 200, 136, 300000
+        tris = scenes.random_clip_triangles(n, W, H, seed=31, spread=1.05)
+        r = fr.Renderer(W, H)
+        f = oracle.Frame(W, H)
+        r.set_count_fragments(False)
+        r.clear()
+        f.clear()
+        r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
+        f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
+        _, d, t = r.readback()
+        np.testing.assert_array_equal(t, f.tri_id)
+        np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+    else:
+        W, H = 320, 200
+        mesh = scenes.displaced_sphere(n=40)
+        tex = scenes.checker_texture(64, 8)
+        eye, at, up, fovy, aspect, zn, zf = scenes.demo_camera(W, H)
+        r = fr.Renderer(W, H)
+        r.set_texture(0, tex)
+        r.set_uniforms(view=fr.set_look_at(eye, at, up), proj=fr.set_perspective(fovy, aspect, zn, zf), view_pos=eye, texture_slot=0)
+        r.clear()
+        r.draw(r.upload_mesh(mesh, fr.VS_PHONG), fr.PS_PHONG)
+        f = oracle.Frame(W, H)
+        f.clear()
+        u = oracle.make_uniforms(view=oracle.set_look_at(eye, at, up), proj=oracle.set_perspective(fovy, aspect, zn, zf),
+                                 view_pos=eye, tex=oracle.Texture(tex))
+        f.draw(mesh, oracle.VS_PHONG, oracle.PS_PHONG, u)
+        c, d, t = r.readback()
+        np.testing.assert_array_equal(t, f.tri_id)
+        np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+        np.testing.assert_array_equal(c, f.color)
+
+
+def test_mixed_geometry_paths_across_draws(oracle):
+    """The per-draw slots (group sums, clipped-triangle counter) alternate per draw whichever path a draw takes:
+    self-summing emit (<= 8192 count blocks), k_scan_blocks (more than 2,097,152 triangles) and the empty mesh must
+    each leave the other slot clean for the draw after them -- small -> 2.2M triangles -> small, over two frames,
+    then small -> empty -> small with clipped triangles."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H = 256, 144
+    small = scenes.random_clip_triangles(5000, W, H, seed=41, spread=1.3)          # many clipped triangles
+    big = scenes.random_clip_triangles(2_200_000, 8 * W, 8 * H, seed=42)            # 8593 count blocks; tiny triangles
+    empty = np.zeros((0, 3, 4), np.float32)
+    r = fr.Renderer(W, H)
+    f = oracle.Frame(W, H)
+    u = oracle.make_uniforms()
+    ms, mb, me = r.upload_mesh(small, fr.VS_CLIP), r.upload_mesh(big, fr.VS_CLIP), r.upload_mesh(empty, fr.VS_CLIP)
+    for seq in (((ms, small), (mb, big), (ms, small)), ((ms, small), (mb, big), (ms, small)),
+                ((ms, small), (me, empty), (ms, small)), ((me, empty), (ms, small), (me, empty), (ms, small))):
+        r.clear()
+        f.clear()
+        f.counters = oracle.Counters()
+        base = 0
+        for mesh, arr in seq:
+            r.draw(mesh, fr.PS_DEPTH)
+            if arr.shape[0]:
+                f.draw(arr, oracle.VS_CLIP, oracle.PS_DEPTH, u, tri_id_base=base)
+            base = int(f.counters.tris_setup)
+        _, d, t = r.readback()
+        np.testing.assert_array_equal(t, f.tri_id)
+        np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+        st = r.stats()
+        assert st["tris_setup"] == f.counters.tris_setup and st["overflow"] == 0
+
+
+def test_filtered_setup_list_is_not_reused(oracle):
+    """frr_draw on a partitioned ctx filters the setup list by the rank's tile rows of its window; frr_raster with
+    another window / partition and frr_readback_setup must refuse it (FRR_ERR_INVALID) instead of silently
+    dropping triangles, and the unfiltered frr_geometry path serves any number of windows (renderer.rs:269-271)."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H = 256, 160
+    tris = scenes.random_clip_triangles(4000, W, H, seed=43)
+    r = fr.Renderer(W, H)
+    m = r.upload_mesh(tris, fr.VS_CLIP)
+    r.set_partition(1, 2)
+    r.clear()
+    r.draw(m, fr.PS_DEPTH)
+    with pytest.raises(fr.FrrError) as e:
+        r.rasterization((0, W), (0, H // 2), fr.PS_DEPTH)
+    assert e.value.code == fr.FRR_ERR_INVALID
+    with pytest.raises(fr.FrrError):
+        r.setup_triangles()
+    r.set_partition(0, 2)
+    with pytest.raises(fr.FrrError):
+        r.rasterization((0, W), (0, H), fr.PS_DEPTH)
+    # the unfiltered list: two windows of one geometry on a partitioned ctx, both ranks stitched == oracle
+    f = oracle.Frame(W, H)
+    f.clear()
+    f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
+    full_d = np.zeros(W * H, np.float32)
+    full_t = np.full(W * H, 0xFFFFFFFF, np.uint32)
+    for rank in range(2):
+        r.set_partition(rank, 2)
+        r.clear()
+        n = r.geometry_processing(m, count=True)
+        assert n == f.counters.tris_setup
+        assert r.setup_triangles().shape[0] == n
+        r.rasterization((0, W), (0, H), fr.PS_DEPTH)
+        _, d, t = r.readback()
+        rows = np.arange(H) // 32 % 2 == rank
+        mask = np.repeat(rows, W)
+        full_d[mask] = d[mask]
+        full_t[mask] = t[mask]
+    np.testing.assert_array_equal(full_t, f.tri_id)
+    np.testing.assert_array_equal(full_d.view(np.uint32), f.depth.view(np.uint32))
