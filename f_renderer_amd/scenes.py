@@ -171,7 +171,7 @@ CONFIG_NAMES = ("cfg1", "cfg2", "cfg3", "cfg3b", "cfg4", "cfg5", "headline")
 def build_config(name, reduced=False):
     """One BASELINE.json config as plain data: dict(name, W, H, mesh [n,3,NF] f32, vs, ps (names of
     the shader-table entries), cam (use demo_camera), tex (RGBA8 or None), flat_color).  `reduced`: the same
-    scene at 1/8 of the linear frame size with a coarser mesh -- what the CPU-only tests and the NumPy oracle
+    scene at 1/8 of the linear frame size with a coarser mesh -- what the CPU-only checkers
     can afford."""
     flat = (1.0, 0.5, 0.25, 1.0)
     r = bool(reduced)
