@@ -4,19 +4,25 @@
 Metric (BASELINE.json): Mtri/s + Mfrag/s on a synthetic 1M-triangle frame @1920x1080.
 A "step" = one frame of the hot path over resident inputs: frr_clear + frr_draw (geometry ->
 binning -> tile raster/resolve) [+ the RCCL image gather when N > 1].  Inputs (the triangle
-list) are in HBM before the timed region starts.
+list, textures) are in HBM before the timed region starts.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload headline|cfg2|cfg3|cfg4|cfg5] [--also cfg4,cfg5]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Multi-GPU: one process per GPU; the framebuffer is partitioned into N contiguous blocks of 32-px tile
-rows (frr_set_partition_layout: blocked), geometry is replicated, and the only collective is one RCCL
-gather of the owned slabs to rank 0 per frame, read straight from the render target and overlapped with
-the next frame.  Total work is fixed => "scaling": "strong".
+rows (frr_set_partition_layout: blocked), geometry is replicated, and the only collective is the RCCL
+gather of the owned slabs (depth for depth-only workloads, colour + depth for shaded ones) to rank 0 per
+frame, read straight from the render targets and overlapped with the next frames.  Before the timed region
+rank 0 renders the same frame unpartitioned; the gathered image of the LAST timed frame must equal it byte
+for byte (depth bits, RGBA8, and -- in one extra check frame -- triangle ids).  Total work is fixed =>
+"scaling": "strong".
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).  `--also` (default: the 4096^2
+and the 4K textured configs north_star's scaling target is quoted on) runs further workloads after the primary
+one, fewer steps each, and reports them under "secondary" with the same fields.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,12 +33,17 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+# name -> (config of f_renderer_amd.scenes.build_config, text)
 WORKLOADS = {
-    # name: (width, height, ntris, vs, ps)
-    "random_1M_tris_1920x1080_depth": (1920, 1080, 1_000_000, "clip", "depth"),
-    "random_1M_tris_4096x4096_depth": (4096, 4096, 1_000_000, "clip", "depth"),
+    "random_1M_tris_1920x1080_depth": ("headline", "1M random clip-space triangles, 1920x1080, depth-only"),
+    "random_1M_tris_4096x4096_depth": ("cfg4", "1M random clip-space triangles, 4096x4096, depth-only"),
+    "sheets_259k_tris_3840x2160_blinn": ("cfg5", "250,000-triangle layered sheets, 3840x2160, textured Blinn-Phong"),
+    "sphere_69k_tris_1920x1080_phong": ("cfg3", "69,192-triangle displaced sphere, 1920x1080, textured Phong"),
+    "torus_6k_tris_1920x1080_gouraud": ("cfg2", "6,272-triangle torus, 1920x1080, Gouraud"),
 }
+ALIASES = {cfg: name for name, (cfg, _) in WORKLOADS.items()}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROF_PERIOD = 4        # HIP events around the dominant kernel only, every 4th launch (a pair costs the stream ~4 us)
 
 
 def parse_args():
@@ -40,24 +51,70 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="random_1M_tris_1920x1080_depth", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="random_1M_tris_1920x1080_depth", choices=sorted(WORKLOADS) + sorted(ALIASES))
+    ap.add_argument("--also", default="cfg4,cfg5",
+                    help="comma-separated further workloads reported under 'secondary' (fewer steps each); 'none' disables")
     ap.add_argument("--force-dist", action="store_true",
-                    help="dev: initialise RCCL and run the band gather even with one rank (exercises the N>1 code path)")
+                    help="dev: initialise RCCL and run the slab gather even with one rank (exercises the N>1 code path)")
     ap.add_argument("--sync-gather", action="store_true",
-                    help="N > 1: wait for each frame's gather before rendering the next one (default: the gather of "
-                         "frame i overlaps the rendering of frame i+1 into a second target set)")
-    ap.add_argument("--gather-rows-div", type=int, default=1,
-                    help="dev, with --force-dist on one rank: gather only 1/D of the rows (a band of the size a rank of D would send)")
+                    help="N > 1: wait for each frame's gather before rendering the next one (default: the gathers of "
+                         "frames i-1, i-2 overlap the rendering of frame i into other target sets)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0,
                     help="approximate CPU time budget of the oracle baseline leg (rank 0, N=1 only); 0 disables")
     return ap.parse_args()
 
 
-def cpu_baseline(tris, W, H, budget_s):
+def source_sha():
+    """Digest of the kernel sources the loaded library was built from (profiles/pmc_traffic.json entries carry the
+    digest they were measured on; a stale entry is not reported)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "f_renderer_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".h", ".hip")):
+            with open(os.path.join(d, fn), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc_traffic(workload):
+    """(HBM bytes per k_raster launch, stale?) from a committed rocprofv3 --pmc run (profiles/pmc_traffic.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            d = json.load(fh)
+        e = d.get(workload, {})
+        k = e.get("k_raster")
+        if not k:
+            return None, False
+        if e.get("_source_sha") != source_sha():
+            return None, True
+        return float(k["hbm_bytes_per_launch"]), False
+    except Exception:
+        return None, False
+
+
+def golden_counts(cfg_name):
+    """tris_setup / frag_covered / frag_zpass of the full-size config from the committed digests (data only)."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "frames.json")) as fh:
+            return json.load(fh)[cfg_name]["full"]
+    except Exception:
+        return None
+
+
+def cpu_baseline(cfg, budget_s):
     """Times the CPU oracle (oracle/frr_oracle.c, single thread) on whole frames of the SAME
-    workload.  Returns (dict for the JSON line, oracle counters of one frame)."""
+    workload.  Returns (dict for the JSON line, oracle counters of one frame, all-core best-effort dict)."""
     from oracle import cref
-    u = cref.make_uniforms()
+    from f_renderer_amd import scenes
+    W, H, mesh = cfg["W"], cfg["H"], cfg["mesh"]
+    vs, ps = getattr(cref, "VS_" + cfg["vs"]), getattr(cref, "PS_" + cfg["ps"])
+    kw = {}
+    if cfg["cam"]:
+        eye, at, up, fovy, aspect, zn, zf = scenes.demo_camera(W, H)
+        kw = dict(view=cref.set_look_at(eye, at, up), proj=cref.set_perspective(fovy, aspect, zn, zf), view_pos=eye)
+    if cfg["tex"] is not None:
+        kw["tex"] = cref.Texture(cfg["tex"])
+    u = cref.make_uniforms(flat_color=cfg["flat_color"], **kw)
     f = cref.Frame(W, H)
     reps, total, counters = 0, 0.0, None
     while reps == 0 or (total < budget_s and reps < 64):
@@ -65,37 +122,260 @@ def cpu_baseline(tris, W, H, budget_s):
         f.clear((30, 30, 30, 255), 0.0)
         t0 = time.perf_counter()
         f.clear((30, 30, 30, 255), 0.0)
-        f.draw(tris, cref.VS_CLIP, cref.PS_DEPTH, u)
+        f.draw(mesh, vs, ps, u)
         total += time.perf_counter() - t0
         reps += 1
         counters = f.counters.as_dict()
-    ntris = tris.shape[0]
-    return {
+    ntris = mesh.shape[0]
+    base = {
         "value": ntris * reps / total / 1e6, "unit": "Mtri/s", "cores": 1, "kind": "port",
         "mfrag_per_s": counters["frag_covered"] * reps / total / 1e6,
         "sample": f"{reps} whole frame(s) of the same workload ({ntris} tris), clear+geometry+raster, "
                   f"{total:.1f} s on 1 of {os.cpu_count()} host cores; C restatement of renderer.rs "
                   f"(oracle/frr_oracle.c), optimistic: omits the reference's per-triangle heap allocations",
-    }, counters
+    }
+    # SURVEY 8d's "best-effort all-core CPU": the same code with the rows split over host threads through the
+    # reference's own sub-window argument; NOT the baseline (the reference is single-threaded)
+    threads = min(os.cpu_count() or 1, 64)
+    _, _, _, cov, secs = cref.draw_banded(W, H, mesh, vs, ps, u, threads=threads)
+    best = {"value": ntris / secs / 1e6, "unit": "Mtri/s", "cores": threads, "seconds": round(secs, 3),
+            "note": "row bands over host threads via the sub-window argument (renderer.rs:270-271); every band repeats "
+                    "the geometry of all triangles, which is what the reference's per-triangle API offers; not the baseline"}
+    return base, counters, best
 
 
-def load_pmc_traffic(workload):
-    """HBM bytes per k_raster launch from a committed rocprofv3 --pmc run (profiles/*.json), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(p) as fh:
-            d = json.load(fh)
-        e = d.get(workload, {}).get("k_raster")
-        return float(e["hbm_bytes_per_launch"]) if e else None
-    except Exception:
-        return None
+class Run:
+    """One workload on this rank: contexts, targets, gathers."""
+
+    def __init__(self, args, torch, dist, rank, world, local_rank, name):
+        import f_renderer_amd as fr
+        from f_renderer_amd import scenes
+        from f_renderer_amd.multigpu import FrameGather, band_layout
+        self.args, self.torch, self.dist, self.rank, self.world, self.fr = args, torch, dist, rank, world, fr
+        self.name = name
+        self.cfg_name = WORKLOADS[name][0]
+        cfg = self.cfg = scenes.build_config(self.cfg_name)        # same arrays on every rank (deterministic)
+        W, H = self.W, self.H = cfg["W"], cfg["H"]
+        self.ntris = int(cfg["mesh"].shape[0])
+        self.vs, self.ps = getattr(fr, "VS_" + cfg["vs"]), getattr(fr, "PS_" + cfg["ps"])
+        self.K = fr.lib().frr_vs_num_varyings(self.vs)
+        self.shaded = cfg["ps"] != "DEPTH"
+        self.stream = torch.cuda.Stream()
+        with torch.cuda.stream(self.stream):
+            # frame targets live in torch tensors (plumbing: device memory + the gather's operands); the height is
+            # padded to a whole number of tile rows per rank so that every rank's slab has the same size
+            _, _, HP = band_layout(H, world)
+            self.HP = HP
+            # three target sets: frame i renders into set i % 3 while the gathers of frames i-1 and i-2 may still be
+            # in flight; before a set is reused the HOST checks that its gather (three frames back) has completed
+            self.nsets = 3 if dist is not None else 1
+            mk = lambda dt, fill: [torch.full((HP, W), fill, dtype=dt, device="cuda") for _ in range(self.nsets)]  # noqa: E731
+            self.color, self.depth, self.tri_id = mk(torch.int32, 0), mk(torch.float32, 0.0), mk(torch.int32, -1)
+            self.r = self.make_renderer(local_rank)
+            self.r.bind_targets(self.color[0].data_ptr(), self.depth[0].data_ptr(), self.tri_id[0].data_ptr())
+            self.r.set_partition(rank, world, blocked=True)   # contiguous slabs: the gather needs no staging copies
+            self.dev_in = torch.from_numpy(cfg["mesh"]).to("cuda")  # resident in HBM before timing
+            self.mesh = self.r.bind_mesh_device(self.dev_in.data_ptr(), self.ntris, self.vs, keepalive=self.dev_in)
+            self.gathers, self.gather_ids = None, None
+            if dist is not None:
+                planes = ([(torch.int32, ())] if self.shaded else []) + [(torch.float32, ())]
+                self.gathers = [FrameGather(H, W, planes, "cuda", rank, world) for _ in range(self.nsets)]
+                self.gather_ids = FrameGather(H, W, [(torch.int32, ())], "cuda", rank, world)
+            self.inflight = [None] * self.nsets
+            self.final = None
+            self.frame_no = 0
+            self.local_rank = local_rank
+
+    def make_renderer(self, local_rank):
+        fr, cfg = self.fr, self.cfg
+        from f_renderer_amd import scenes
+        r = fr.Renderer(self.W, self.H, device=local_rank, stream=self.stream.cuda_stream)
+        kw = {}
+        if cfg["cam"]:
+            eye, at, up, fovy, aspect, zn, zf = scenes.demo_camera(self.W, self.H)
+            kw = dict(view=fr.set_look_at(eye, at, up), proj=fr.set_perspective(fovy, aspect, zn, zf), view_pos=eye)
+        if cfg["tex"] is not None:
+            r.set_texture(0, cfg["tex"])
+            kw["texture_slot"] = 0
+        r.set_uniforms(flat_color=cfg["flat_color"], **kw)
+        return r
+
+    def planes_of(self, s):
+        return ([self.color[s]] if self.shaded else []) + [self.depth[s]]
+
+    def drain(self):
+        for s in range(self.nsets):
+            if self.inflight[s] is not None:
+                self.final = self.gathers[s].finish(self.inflight[s])
+                self.inflight[s] = None
+
+    def step(self, gather=True, sync_gather=None):
+        sync_gather = self.args.sync_gather if sync_gather is None else sync_gather
+        s = self.frame_no % self.nsets
+        self.frame_no += 1
+        g = self.gathers if gather else None
+        if self.gathers is not None:
+            if self.inflight[s] is not None:            # the gather that last read this target set must be done
+                self.final = self.gathers[s].finish(self.inflight[s]) if sync_gather else self.gathers[s].finish_host(self.inflight[s])
+                self.inflight[s] = None
+            self.r.bind_targets(self.color[s].data_ptr(), self.depth[s].data_ptr(), self.tri_id[s].data_ptr())
+        self.r.clear((30, 30, 30, 255), 0.0)
+        self.r.draw(self.mesh, self.ps)
+        if g is not None:
+            # owned slabs -> the RCCL gather to rank 0 (final image only), overlapped with the next frames
+            self.inflight[s] = g[s].start(self.planes_of(s))
+            if sync_gather:
+                self.final = g[s].finish(self.inflight[s])
+                self.inflight[s] = None
+        return s
+
+    def reference_image(self):
+        """Rank 0: the same frame rendered unpartitioned by a second context -> (colour, depth, ids) tensors."""
+        torch = self.torch
+        r = self.make_renderer(self.local_rank)
+        c = torch.zeros((self.H, self.W), dtype=torch.int32, device="cuda")
+        d = torch.zeros((self.H, self.W), dtype=torch.float32, device="cuda")
+        t = torch.full((self.H, self.W), -1, dtype=torch.int32, device="cuda")
+        r.bind_targets(c.data_ptr(), d.data_ptr(), t.data_ptr())
+        m = r.bind_mesh_device(self.dev_in.data_ptr(), self.ntris, self.vs, keepalive=self.dev_in)
+        r.set_count_fragments(False)
+        r.clear((30, 30, 30, 255), 0.0)
+        r.draw(m, self.ps)
+        r.sync()
+        if r.stats()["overflow"]:
+            raise SystemExit("device work list overflow in the reference render")
+        r.close()
+        return c, d, t
+
+    def timed_loop(self, n, **kw):
+        torch, dist = self.torch, self.dist
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            self.step(**kw)
+        self.drain()                      # every frame's image has reached rank 0 inside the timed region
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def run(self, steps, warmup, primary):
+        torch, dist, r = self.torch, self.dist, self.r
+        with torch.cuda.stream(self.stream):
+            ref = self.reference_image() if (self.gathers is not None and self.rank == 0) else None
+            # one counted frame: the exact covered-fragment count of this rank's tiles (the Mfrag/s
+            # numerator).  The statistic is then switched off: maintaining it forbids the tile kernel's
+            # whole-triangle early-z (outputs are identical either way, tests/test_gpu_earlyz.py).
+            r.set_count_fragments(True)
+            self.step()
+            self.drain()
+            r.sync()
+            counted = r.stats()
+            r.set_count_fragments(False)
+            for _ in range(warmup):
+                self.step()
+            self.drain()
+            r.sync()
+            stats = r.stats()
+            if stats["overflow"] or counted["overflow"]:
+                raise SystemExit("device work list overflow during warmup")
+
+            r.profile_reset()
+            r.profile_enable(True, kernels=["k_raster"], period=PROF_PERIOD)
+            elapsed = self.timed_loop(steps)
+            raster_ms, raster_n = r.profile_get("k_raster")
+            r.profile_enable(False)
+            stats = r.stats()
+
+            # multi-GPU image check on rank 0: the gathered image of the LAST timed frame == the unpartitioned render,
+            # byte for byte; triangle ids through one extra (untimed) frame's gather
+            image_equal = None
+            render_us = gather_us = None
+            if self.gathers is not None:
+                s = self.step(gather=False)
+                ids_final = self.gather_ids([self.tri_id[s]])
+                torch.cuda.synchronize()
+                if self.rank == 0:
+                    H = self.H
+                    bits = lambda x: x.view(torch.int32)  # noqa: E731
+                    got = list(self.final)
+                    want = ([ref[0]] if self.shaded else []) + [ref[1]]
+                    image_equal = all(bool(torch.equal(bits(g[:H]), bits(w))) for g, w in zip(got, want))
+                    image_equal = image_equal and bool(torch.equal(ids_final[0][:H], ref[2]))
+                # render and gather separately (max over ranks): a render-only loop, then the same loop with a gather
+                # that is waited for every frame (serial, nothing overlapped)
+                n2 = max(4, min(steps, 20))
+                t_render = self.timed_loop(n2, gather=False)
+                t_both = self.timed_loop(n2, sync_gather=True)
+                render_us, gather_us = t_render / n2 * 1e6, max(0.0, (t_both - t_render) / n2 * 1e6)
+
+        t = torch.tensor([elapsed, render_us or 0.0, gather_us or 0.0], dtype=torch.float64, device="cuda")
+        cov = torch.tensor([float(counted["frag_covered"])], dtype=torch.float64, device="cuda")
+        if dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(cov, op=dist.ReduceOp.SUM)
+        elapsed = float(t[0].item())
+        frag_covered = int(cov.item())  # covered fragments of one frame over all ranks' tiles
+        if self.rank != 0:
+            return None
+        world, W, H, ntris = self.world, self.W, self.H, self.ntris
+        ms_per_step = elapsed / steps * 1e3
+        mtri = ntris / (ms_per_step * 1e-3) / 1e6
+        mfrag = frag_covered / (ms_per_step * 1e-3) / 1e6
+        gathered = ("colour + depth" if self.shaded else "depth")
+        out = {
+            "value": round(mtri, 3), "unit": "Mtri/s", "mfrag_per_s": round(mfrag, 1),
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 5),
+            "config": {"workload": self.name, "scene": WORKLOADS[self.name][1], "width": W, "height": H, "triangles": ntris,
+                       "setup_triangles": stats["tris_setup"] if world == 1 else None, "covered_fragments": frag_covered,
+                       "shader": f"VS_{self.cfg['vs']}/PS_{self.cfg['ps']}", "varyings": self.K, "tile": "32x32",
+                       "partition": f"tile rows in {world} contiguous block(s)" + (f", RCCL gather of {gathered} to rank 0" if self.gathers is not None else "")},
+        }
+        if image_equal is not None:
+            out["gathered_image_equal"] = image_equal
+            out["render_us_max"] = round(float(t[1].item()), 2)
+            out["gather_us_max"] = round(float(t[2].item()), 2)
+        self._raster = (raster_ms, raster_n)
+        self._stats = stats
+        self._frag_covered = frag_covered
+        return out
+
+    def roofline(self, out, f_pass, n_setup):
+        """Roofline of the dominant kernel (k_raster): algorithmic bytes per launch:
+          N_setup * (108 + 12K) record bytes read by the raster pass
+        + 4 B depth read per covered fragment + 8 B (depth+colour/id write) per z-passing fragment."""
+        raster_ms, raster_n = self._raster
+        if not raster_n:
+            return
+        avg_ms = raster_ms / raster_n
+        if self.world == 1 and f_pass is not None:
+            alg = n_setup * (108 + 12 * self.K) + 4 * self._frag_covered + 8 * f_pass
+            ach = alg / (avg_ms * 1e-3) / 1e9
+            traffic, stale = load_pmc_traffic(self.name)
+            out["roofline"] = {"bound": "hbm", "kernel": "k_raster", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg_ms, 5),
+                               "launches": raster_n, "sampled_every": PROF_PERIOD, "frag_zpass": f_pass,
+                               "note": "achieved = ALGORITHMIC bytes (the reference's memory semantics) / launch time, an efficiency "
+                                       "figure; the kernel resolves depth in LDS, its measured HBM bytes are `traffic`"}
+            if stale:
+                out["roofline"]["traffic_stale"] = "profiles/pmc_traffic.json was measured on other kernel sources"
+        else:
+            out["roofline"] = {"bound": "hbm", "kernel": "k_raster", "achieved": None, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                               "launches": raster_n,
+                               "note": "per-rank launch covers 1/N of the tiles; algorithmic bytes are quoted at N=1"}
+
+    def close(self):
+        self.r.close()
 
 
 def main():
     args = parse_args()
     import torch
-    import f_renderer_amd as fr
-    from f_renderer_amd import scenes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -124,154 +404,55 @@ def main():
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    W, H, ntris, _, _ = WORKLOADS[args.workload]
-    tris = scenes.random_clip_triangles(ntris, W, H)  # same arrays on every rank (deterministic)
+    primary = ALIASES.get(args.workload, args.workload)
+    also = [] if args.also.strip().lower() in ("", "none") else [ALIASES.get(a.strip(), a.strip()) for a in args.also.split(",")]
+    also = [a for a in also if a in WORKLOADS and a != primary]
 
-    stream = torch.cuda.Stream()
-    with torch.cuda.stream(stream):
-        r = fr.Renderer(W, H, device=local_rank, stream=stream.cuda_stream)
-        # frame targets live in torch tensors (plumbing: device memory + the gather's operands);
-        # rows are padded to a whole number of tile rows per rank so owned bands are one strided view
-        from f_renderer_amd.multigpu import BlockGather, band_layout
-        _, _, HP = band_layout(H, world)
-        # three target sets: frame i renders into set i % 3 while the gathers of frames i-1 and i-2 may still be in flight;
-        # before a set is reused the HOST checks that its gather (three frames back) has completed
-        nsets = 3 if dist is not None else 1
-        color = [torch.zeros((HP, W), dtype=torch.int32, device="cuda") for _ in range(nsets)]
-        depth = [torch.zeros((HP, W), dtype=torch.float32, device="cuda") for _ in range(nsets)]
-        tri_id = [torch.full((HP, W), -1, dtype=torch.int32, device="cuda") for _ in range(nsets)]
-        r.bind_targets(color[0].data_ptr(), depth[0].data_ptr(), tri_id[0].data_ptr())
-        r.set_partition(rank, world, blocked=True)   # contiguous slabs: the gather needs no staging copies
-        dev_in = torch.from_numpy(tris).to("cuda")  # resident in HBM before timing
-        mesh = r.bind_mesh_device(dev_in.data_ptr(), ntris, fr.VS_CLIP, keepalive=dev_in)
-        gh = H // max(1, args.gather_rows_div) if world == 1 else H
-        gathers = [BlockGather(gh, W, torch.float32, "cuda", rank, world) for _ in range(nsets)] if dist is not None else None
-        ghp = band_layout(gh, world)[2]
-        inflight = [None] * nsets
-        final = None
-        frame_no = 0
+    run = Run(args, torch, dist, rank, world, local_rank, primary)
+    line = run.run(args.steps, args.warmup, True)
+    if rank == 0:
+        H = run.H
+        head = {"metric": "Mtri/s (and Mfrag/s), 1M-triangle frame @1920x1080" if run.cfg_name == "headline" else "Mtri/s (and Mfrag/s) per frame",
+                "value": line["value"], "unit": "Mtri/s", "mfrag_per_s": line["mfrag_per_s"], "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": line["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+        head.update({k: v for k, v in line.items() if k not in head})
+        line = head
+        gold = golden_counts(run.cfg_name)
+        f_pass, n_setup = (gold["frag_zpass"], gold["tris_setup"]) if gold else (None, None)
+        if world == 1 and args.cpu_baseline_seconds > 0:
+            cpu, oc, best = cpu_baseline(run.cfg, args.cpu_baseline_seconds)
+            line["cpu_baseline"] = cpu
+            line["cpu_best_effort"] = best
+            line["parity_counts_match"] = bool(oc["frag_covered"] == run._frag_covered and oc["tris_setup"] == run._stats["tris_setup"]
+                                               and (gold is None or (gold["frag_zpass"] == oc["frag_zpass"] and gold["frag_covered"] == oc["frag_covered"])))
+            line["speedup_vs_cpu_1core"] = round(line["value"] / cpu["value"], 1)
+            f_pass, n_setup = oc["frag_zpass"], oc["tris_setup"]
+        run.roofline(line, f_pass, n_setup)
+    run.close()
+    del run
 
-        def drain():
-            nonlocal final
-            for s in range(nsets):
-                if inflight[s] is not None:
-                    final = gathers[s].finish(inflight[s])
-                    inflight[s] = None
-
-        def step():
-            nonlocal final, frame_no
-            s = frame_no % nsets
-            frame_no += 1
-            if gathers is not None:
-                if inflight[s] is not None:            # the gather that last read this target set must be done
-                    final = gathers[s].finish(inflight[s]) if args.sync_gather else gathers[s].finish_host(inflight[s])
-                r.bind_targets(color[s].data_ptr(), depth[s].data_ptr(), tri_id[s].data_ptr())
-            r.clear((30, 30, 30, 255), 0.0)
-            r.draw(mesh, fr.PS_DEPTH)
-            if gathers is not None:
-                # owned bands -> ONE RCCL gather to rank 0 (final image only), overlapped with the next frame
-                inflight[s] = gathers[s].start(depth[s][:ghp])
-                if args.sync_gather:
-                    final = gathers[s].finish(inflight[s])
-                    inflight[s] = None
-
-        # one counted frame: the exact covered-fragment count of this rank's tiles (the Mfrag/s
-        # numerator).  The statistic is then switched off: maintaining it forbids the tile kernel's
-        # whole-triangle early-z (outputs are identical either way, tests/test_gpu_earlyz.py).
-        r.set_count_fragments(True)
-        step()
-        drain()
-        r.sync()
-        counted = r.stats()
-        r.set_count_fragments(False)
-        for _ in range(args.warmup):
-            step()
-        drain()
-        r.sync()
-        stats = r.stats()
-        if stats["overflow"] or counted["overflow"]:
-            raise SystemExit("device work list overflow during warmup")
-
-        r.profile_reset()
-        PROF_PERIOD = 4  # HIP events around the dominant kernel only, every 4th launch (a pair costs the stream ~4 us)
-        r.profile_enable(True, kernels=["k_raster"], period=PROF_PERIOD)
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        drain()                      # every frame's image has reached rank 0 inside the timed region
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        raster_ms, raster_n = r.profile_get("k_raster")
-        r.profile_enable(False)
-        stats = r.stats()
-
-        # multi-GPU image check on rank 0: gathered image == what a single full render would hold
-        image_ok = None
-        if gathers is not None and rank == 0:
-            # every pixel of the gathered depth image must come from its owner's render (clear value 0 or a
-            # positive 1/w): finite and non-negative everywhere, and not all background
-            img = final[:gh]
-            image_ok = bool(torch.isfinite(img).all().item() and (img >= 0).all().item() and (img > 0).any().item())
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    cov = torch.tensor([float(counted["frag_covered"])], dtype=torch.float64, device="cuda")
-    if dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cov, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    frag_covered = int(cov.item())  # covered fragments of one frame over all ranks' tiles
+    secondary = []
+    for name in also:
+        steps2 = max(4, min(args.steps, 20))
+        r2 = Run(args, torch, dist, rank, world, local_rank, name)
+        o = r2.run(steps2, min(args.warmup, 3), False)
+        if rank == 0:
+            gold = golden_counts(r2.cfg_name)
+            if gold:
+                r2.roofline(o, gold["frag_zpass"], gold["tris_setup"])
+                o["parity_counts_match"] = bool(gold["frag_covered"] == r2._frag_covered)
+            secondary.append(o)
+        r2.close()
+        del r2
 
     if saved_stdout_fd is not None:
         sys.stdout.flush()
         os.dup2(saved_stdout_fd, 1)
         os.close(saved_stdout_fd)
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        mtri = ntris / (ms_per_step * 1e-3) / 1e6
-        mfrag = frag_covered / (ms_per_step * 1e-3) / 1e6
-        line = {
-            "metric": "Mtri/s (and Mfrag/s), 1M-triangle frame @1920x1080" if H == 1080 else "Mtri/s (and Mfrag/s), 1M-triangle frame",
-            "value": round(mtri, 3), "unit": "Mtri/s", "mfrag_per_s": round(mfrag, 1),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "width": W, "height": H, "triangles": ntris,
-                       "setup_triangles": stats["tris_setup"], "covered_fragments": frag_covered,
-                       "shader": "VS_CLIP/PS_DEPTH (depth-only)", "tile": "32x32",
-                       "partition": f"tile rows in {world} contiguous block(s)" + (", RCCL gather to rank 0" if world > 1 else "")},
-        }
-        if image_ok is not None:
-            line["gathered_image_finite"] = image_ok
-        cpu, oc = None, None
-        if world == 1 and args.cpu_baseline_seconds > 0:
-            cpu, oc = cpu_baseline(tris, W, H, args.cpu_baseline_seconds)
-            line["cpu_baseline"] = cpu
-            line["parity_counts_match"] = bool(oc["frag_covered"] == frag_covered and oc["tris_setup"] == stats["tris_setup"])
-            line["speedup_vs_cpu_1core"] = round(mtri / cpu["value"], 1)
-        # roofline of the dominant kernel (k_raster): algorithmic bytes per launch:
-        #   N_setup * (108 + 12K) record bytes read by the raster pass          (K = 0 here)
-        # + 4 B depth read per covered fragment + 8 B (depth+colour/id write) per z-passing fragment
-        if raster_n:
-            avg_ms = raster_ms / raster_n
-            f_pass = oc["frag_zpass"] if oc else None
-            if world == 1 and f_pass is not None:
-                alg = stats["tris_setup"] * 108 + 4 * frag_covered + 8 * f_pass
-                ach = alg / (avg_ms * 1e-3) / 1e9
-                line["roofline"] = {"bound": "hbm", "kernel": "k_raster", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                    "traffic": load_pmc_traffic(args.workload),
-                                    "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg_ms, 5),
-                                    "launches": raster_n, "sampled_every": PROF_PERIOD, "frag_zpass": f_pass}
-            else:
-                line["roofline"] = {"bound": "hbm", "kernel": "k_raster", "achieved": None, "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 5),
-                                    "launches": raster_n,
-                                    "note": "per-rank launch covers 1/N of the tiles; algorithmic bytes are quoted at N=1"}
+        if secondary:
+            line["secondary"] = secondary
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -3,7 +3,12 @@
 // with the window/Vulkan presentation (out of scope) replaced by a raw RGBA dump and a PPM.
 //
 //   phong_headless <mesh.f32> <ntris> <tex.rgba> <tex_size> <W> <H> <out.rgba> [<out.ppm>]
-// mesh.f32: ntris x 3 x 8 float32 (pos3, uv2, normal3 = VSInput, phong.rs:49-54)
+//       mesh.f32: ntris x 3 x 8 float32 (pos3, uv2, normal3 = VSInput, phong.rs:49-54)
+//   phong_headless --assets <model.obj> <diffuse.tga> <W> <H> <out.rgba> [<out.ppm>]
+//       the reference's own asset formats: Model::new (obj_loader.rs:15-97) + init_vertex_input (phong.rs:187-201)
+//       and FrameBuffer::load_file (renderer.rs:427-471, BGRA storage)
+//   phong_headless --dump-assets <model.obj> <diffuse.tga> <mesh_out.f32> <tex_out.rgba>
+//       loaders only (no GPU): what the two loaders produce, for the CPU-side check against the Python mirror
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,17 +26,47 @@ static std::vector<char> slurp(const char *path)
 
 int main(int argc, char **argv)
 {
-    if (argc < 8) { std::cerr << "usage: phong_headless mesh.f32 ntris tex.rgba tex_size W H out.rgba [out.ppm]\n"; return 2; }
-    const uint64_t ntris = std::strtoull(argv[2], nullptr, 10);
-    const uint32_t ts = (uint32_t)std::atoi(argv[4]), W = (uint32_t)std::atoi(argv[5]), H = (uint32_t)std::atoi(argv[6]);
+    const std::string mode = argc > 1 ? argv[1] : "";
+    if (mode == "--dump-assets") {
+        if (argc < 6) { std::cerr << "usage: phong_headless --dump-assets model.obj diffuse.tga mesh_out.f32 tex_out.rgba\n"; return 2; }
+        try {
+            const frr::Model model(argv[2]);
+            const auto vin = model.vertex_inputs();
+            const frr::FrameBuffer tex = frr::FrameBuffer::load_file(argv[3]);
+            std::ofstream(argv[4], std::ios::binary).write(reinterpret_cast<const char *>(vin.data()), (std::streamsize)(vin.size() * sizeof(vin[0])));
+            std::ofstream(argv[5], std::ios::binary).write(reinterpret_cast<const char *>(tex.get_data().data()), tex.get_size());
+            std::printf("faces=%zu tex=%ux%u\n", model.faces_len(), tex.width(), tex.height());
+        } catch (const frr::Error &e) { std::cerr << e.what() << "\n"; return 1; }
+        return 0;
+    }
+    const bool assets = mode == "--assets";
+    if ((assets && argc < 7) || (!assets && argc < 8)) {
+        std::cerr << "usage: phong_headless mesh.f32 ntris tex.rgba tex_size W H out.rgba [out.ppm]\n"
+                     "       phong_headless --assets model.obj diffuse.tga W H out.rgba [out.ppm]\n";
+        return 2;
+    }
+    const int a0 = assets ? 4 : 5;                                             // index of W
+    const uint32_t W = (uint32_t)std::atoi(argv[a0]), H = (uint32_t)std::atoi(argv[a0 + 1]);
+    const char *out_rgba = argv[a0 + 2], *out_ppm = argc > a0 + 3 ? argv[a0 + 3] : nullptr;
     try {
-        const auto mesh_bytes = slurp(argv[1]);
-        const auto tex_bytes = slurp(argv[3]);
-        if (mesh_bytes.size() != ntris * 96 || tex_bytes.size() != (size_t)ts * ts * 4) { std::cerr << "size mismatch\n"; return 2; }
+        std::vector<std::array<frr::VSInput, 3>> vin;
+        frr::FrameBuffer diffuse(1, 1);
+        if (assets) {
+            vin = frr::Model(argv[2]).vertex_inputs();                        // phong.rs:166, 187-201
+            diffuse = frr::FrameBuffer::load_file(argv[3]);                   // phong.rs:167
+        } else {
+            const uint64_t ntris = std::strtoull(argv[2], nullptr, 10);
+            const uint32_t ts = (uint32_t)std::atoi(argv[4]);
+            const auto mesh_bytes = slurp(argv[1]);
+            const auto tex_bytes = slurp(argv[3]);
+            if (mesh_bytes.size() != ntris * 96 || tex_bytes.size() != (size_t)ts * ts * 4) { std::cerr << "size mismatch\n"; return 2; }
+            vin.resize(ntris);
+            std::memcpy(vin.data(), mesh_bytes.data(), mesh_bytes.size());
+            diffuse = frr::FrameBuffer(ts, ts);                               // FrameBuffer::load_file stand-in
+            std::memcpy(diffuse.get_data_mut().data(), tex_bytes.data(), tex_bytes.size());
+        }
 
         frr::Renderer renderer(W, H);
-        frr::FrameBuffer diffuse(ts, ts);                                     // FrameBuffer::load_file stand-in
-        std::memcpy(diffuse.get_data_mut().data(), tex_bytes.data(), tex_bytes.size());
         renderer.set_texture(0, diffuse);
 
         frr::Camera camera_1({0.0f, 1.0f, 3.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 1.0f, 0.0f});       // phong.rs:158-162 (at: SURVEY 8d)
@@ -44,7 +79,7 @@ int main(int argc, char **argv)
         renderer.uniforms.texture_slot = 0;                                                     // PSUniform.place
         renderer.set_uniforms();
 
-        frr::Mesh mesh = renderer.upload_mesh_raw(reinterpret_cast<const float *>(mesh_bytes.data()), ntris, FRR_VS_PHONG);
+        frr::Mesh mesh = renderer.upload_mesh(vin, FRR_VS_PHONG);
         frr::FrameBuffer frame_buffer = frr::FrameBuffer::create(W, H);                         // phong.rs:207
 
         renderer.clear({30, 30, 30, 255}, 0.0f);                                                // phong.rs:316-317
@@ -55,9 +90,9 @@ int main(int argc, char **argv)
         const frr_stats st = renderer.stats();
         std::printf("tris_in=%llu tris_setup=%llu frag_covered=%llu\n", (unsigned long long)st.tris_in,
                     (unsigned long long)st.tris_setup, (unsigned long long)st.frag_covered);
-        std::ofstream(argv[7], std::ios::binary).write(reinterpret_cast<const char *>(frame_buffer.get_data().data()), frame_buffer.get_size());
-        if (argc > 8) {
-            std::ofstream ppm(argv[8], std::ios::binary);
+        std::ofstream(out_rgba, std::ios::binary).write(reinterpret_cast<const char *>(frame_buffer.get_data().data()), frame_buffer.get_size());
+        if (out_ppm) {
+            std::ofstream ppm(out_ppm, std::ios::binary);
             ppm << "P6\n" << W << " " << H << "\n255\n";
             for (uint32_t i = 0; i < W * H; ++i) ppm.write(reinterpret_cast<const char *>(&frame_buffer.get_data()[(size_t)i * 4]), 3);
         }

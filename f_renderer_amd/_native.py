@@ -100,6 +100,8 @@ SIGNATURES = {
     "frr_last_error": (C.c_char_p, [C.c_void_p]),
     "frr_set_partition": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "frr_set_partition_layout": (C.c_int, [C.c_void_p, C.c_int]),
+    "frr_owned_band_count": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "frr_owned_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
     "frr_set_count_fragments": (C.c_int, [C.c_void_p, C.c_int]),
     "frr_bind_targets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frr_target_ptrs": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_void_p)]),

@@ -386,6 +386,42 @@ int frr_set_partition_layout(frr_ctx *c, int blocked)
     c->part_blocked = blocked != 0;
     return FRR_OK;
 }
+// owned tile rows of a window of `wh` pixel rows, by the same rule the kernels use (owns_tile_row)
+static int owned_band(const frr_ctx *c, int64_t wh, int band, int32_t *row0, int32_t *row1)
+{
+    const int tiles_y = (int)((wh + TILE - 1) / TILE);
+    if (c->world <= 1) {
+        if (row0) { *row0 = 0; *row1 = (int32_t)wh; }
+        return wh > 0 ? 1 : 0;
+    }
+    if (c->part_blocked) {
+        const int rpr = std::max(1, (tiles_y + c->world - 1) / c->world);
+        const int t0 = c->rank * rpr, t1 = std::min(tiles_y, (c->rank + 1) * rpr);
+        if (t1 <= t0) return 0;
+        if (row0) { *row0 = t0 * TILE; *row1 = (int32_t)std::min<int64_t>(wh, (int64_t)t1 * TILE); }
+        return 1;
+    }
+    const int n = tiles_y > c->rank ? (tiles_y - c->rank + c->world - 1) / c->world : 0;
+    if (row0 && band < n) {
+        const int ty = c->rank + band * c->world;
+        *row0 = ty * TILE; *row1 = (int32_t)std::min<int64_t>(wh, (int64_t)(ty + 1) * TILE);
+    }
+    return n;
+}
+int frr_owned_band_count(const frr_ctx *c, int32_t y0, int32_t y1)
+{
+    if (!c || y0 > y1) return FRR_ERR_INVALID;
+    return owned_band(c, (int64_t)y1 - y0, 0, nullptr, nullptr);
+}
+int frr_owned_rows(const frr_ctx *c, int32_t y0, int32_t y1, int32_t band, int32_t *row0, int32_t *row1)
+{
+    if (!c || y0 > y1 || !row0 || !row1 || band < 0) return FRR_ERR_INVALID;
+    int32_t a = 0, b = 0;
+    const int n = owned_band(c, (int64_t)y1 - y0, band, &a, &b);
+    if (band >= n) return FRR_ERR_INVALID;
+    *row0 = a; *row1 = b;
+    return FRR_OK;
+}
 int frr_set_count_fragments(frr_ctx *c, int enable)
 {
     if (!c) return FRR_ERR_INVALID;

@@ -125,3 +125,27 @@ class BlockGather:
 
     def __call__(self, local_image, group=None):
         return self.finish(self.start(local_image, group))
+
+
+class FrameGather:
+    """The final-image exchange of one frame in the blocked layout: ONE gather per plane (colour, depth, ids ...)
+    of the rank's contiguous slab, straight from the render targets into the final images on `dst`.
+    planes = [(dtype, trailing), ...]; start() takes the rank's padded plane images in the same order."""
+
+    def __init__(self, height, width, planes, device, rank, world, dst=0):
+        self.parts = [BlockGather(height, width, dt, device, rank, world, dst=dst, trailing=tr) for dt, tr in planes]
+        self.rank, self.world, self.dst = rank, world, dst
+        self.padded_height = self.parts[0].padded_height
+
+    def start(self, images, group=None):
+        assert len(images) == len(self.parts)
+        return [p.start(img, group) for p, img in zip(self.parts, images)]
+
+    def finish(self, handles):
+        return [p.finish(h) for p, h in zip(self.parts, handles)]
+
+    def finish_host(self, handles):
+        return [p.finish_host(h) for p, h in zip(self.parts, handles)]
+
+    def __call__(self, images, group=None):
+        return self.finish(self.start(images, group))

@@ -198,6 +198,20 @@ class Renderer:
         self._check(self._lib.frr_set_partition(self._ctx, rank, world))
         self._check(self._lib.frr_set_partition_layout(self._ctx, 1 if blocked else 0))
 
+    def owned_rows(self, height_range=None):
+        """Bands [row0, row1) of window-local pixel rows this rank owns (frr_owned_rows): what the final-image
+        gather of a multi-GPU run sends."""
+        y0, y1 = height_range or (0, self.height)
+        n = self._lib.frr_owned_band_count(self._ctx, y0, y1)
+        if n < 0:
+            raise FrrError(n, "frr_owned_band_count")
+        out = []
+        for b in range(n):
+            a, e = C.c_int32(), C.c_int32()
+            self._check(self._lib.frr_owned_rows(self._ctx, y0, y1, b, C.byref(a), C.byref(e)))
+            out.append((a.value, e.value))
+        return out
+
     def set_count_fragments(self, enable):
         self._check(self._lib.frr_set_count_fragments(self._ctx, 1 if enable else 0))
 

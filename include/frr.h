@@ -111,6 +111,15 @@ int frr_set_partition(frr_ctx *ctx, int rank, int world);
  * k = ceil(tile_rows / world) -- its part of a row-major image is then ONE contiguous slab, so the
  * final-image gather needs no staging copies (bench.py uses this). */
 int frr_set_partition_layout(frr_ctx *ctx, int blocked);
+/* The pixel rows of a raster window height_range = (y0, y1) (renderer.rs:271: the sub-window argument this whole
+ * partition rests on) that this rank owns, as bands [row0, row1) of window-local rows: ONE band in the blocked
+ * layout, one per owned 32-pixel tile row in the interleaved layout; a rank that owns nothing has none.  With
+ * frr_target_ptrs this is all a non-Python host needs for the final-image exchange: the rank's part of a
+ * row-major target of row stride S bytes per row is [row0 * S, row1 * S) of each plane (ncclSend / ncclRecv or
+ * peer stores).  frr_owned_band_count returns the number of bands (>= 0) or a negative
+ * frr_status. */
+int frr_owned_band_count(const frr_ctx *ctx, int32_t y0, int32_t y1);
+int frr_owned_rows(const frr_ctx *ctx, int32_t y0, int32_t y1, int32_t band, int32_t *row0, int32_t *row1);
 /* frr_stats.frag_covered is exact while counting is enabled (default).  Disabling it lets the tile
  * kernel drop whole triangles by hierarchical early-z before their coverage is known (images are
  * identical either way; only the statistic stops being maintained). */

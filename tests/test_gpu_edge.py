@@ -270,3 +270,37 @@ def test_clustered_clipped_triangles(oracle):
         _, d, t = r.readback()
         np.testing.assert_array_equal(t, f.tri_id)
         np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+
+
+@pytest.mark.parametrize("blocked", [False, True])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_owned_rows_are_what_a_partitioned_draw_writes(oracle, world, blocked):
+    """frr_owned_rows (the slab a non-Python host gathers) == the rows a partitioned frr_draw defines: stitching
+    the owned bands of every rank gives the unpartitioned image, and the bands tile the window exactly once."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H = 160, 203                                   # 7 tile rows, the last one 11 pixels high
+    tris = scenes.random_clip_triangles(6000, W, H, seed=77, spread=1.1)
+    f = oracle.Frame(W, H)
+    f.clear()
+    f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
+    got_d = np.full(W * H, -1.0, np.float32)
+    got_t = np.zeros(W * H, np.uint32)
+    seen = np.zeros(H, np.int32)
+    r = fr.Renderer(W, H)
+    m = r.upload_mesh(tris, fr.VS_CLIP)
+    for rank in range(world):
+        r.set_partition(rank, world, blocked=blocked)
+        bands = r.owned_rows()
+        assert all(a % 32 == 0 and a < b <= H for a, b in bands) and (len(bands) <= 1 or not blocked)
+        r.clear()
+        r.draw(m, fr.PS_DEPTH)
+        _, d, t = r.readback()
+        for a, b in bands:
+            seen[a:b] += 1
+            got_d[a * W:b * W] = d[a * W:b * W]
+            got_t[a * W:b * W] = t[a * W:b * W]
+    assert (seen == 1).all()
+    np.testing.assert_array_equal(got_t, f.tri_id)
+    np.testing.assert_array_equal(got_d.view(np.uint32), f.depth.view(np.uint32))
+    assert r.owned_rows((0, 0)) == []

@@ -1,4 +1,4 @@
-"""CPU coverage of the N>1 path (world_size 2, gloo): the band partition + the single gather that
+"""CPU coverage of the N>1 path (world_size 2 and 4, gloo): the band partition + the single gather that
 bench.py runs over RCCL.  Each rank holds the image a partitioned render leaves behind (only its own
 interleaved tile rows written); after the gather rank 0 must hold the full single-GPU image."""
 import os
@@ -54,21 +54,35 @@ def _worker(rank, world, port, H, W, full_np, out_path):
     final_b = bg.finish(bg.start(local_b))
     final_b2 = bg.finish_host(bg.start(local_b))              # bench.py's host-polled completion
     assert (final_b2 is None) == (rank != 0)
+    # bench.py's frame exchange: several planes per frame (RGBA8 as a trailing (4,) u8 image, depth, ids), one gather each
+    from f_renderer_amd.multigpu import FrameGather
+    rgba_full = (full.unsqueeze(-1) * torch.tensor([17.0, 31.0, 59.0, 97.0])).to(torch.uint8)      # [H, W, 4]
+    ids_full = (full * 1000.0).to(torch.int32)
+    local_c = torch.zeros((HP, W, 4), dtype=torch.uint8)
+    local_i = torch.full((HP, W), -1, dtype=torch.int32)
+    if y0 < H:
+        local_c[y0:y1c] = rgba_full[y0:y1c]
+        local_i[y0:y1c] = ids_full[y0:y1c]
+    fg = FrameGather(H, W, [(torch.uint8, (4,)), (torch.float32, ()), (torch.int32, ())], "cpu", rank, world)
+    fin = fg.finish(fg.start([local_c, local_b, local_i]))
+    fin = fg.finish_host(fg.start([local_c, local_b, local_i]))
     if rank == 0:
         assert torch.equal(finals[0][:H], final[:H]) and torch.equal(finals[1][:H], final[:H] * 2.0)
         assert torch.equal(final_b[:H], final[:H])
+        assert torch.equal(fin[0][:H], rgba_full) and torch.equal(fin[1][:H], full) and torch.equal(fin[2][:H], ids_full)
         np.save(out_path, final[:H].numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("H,W", [(1080, 64), (100, 48), (32, 16)])
-def test_band_gather_world2_gloo(tmp_path, H, W):
+@pytest.mark.parametrize("world,H,W", [(2, 1080, 64), (2, 100, 48), (2, 32, 16), (4, 1080, 32), (4, 70, 16)])
+def test_band_gather_gloo(tmp_path, world, H, W):
+    """world 2 and 4; (4, 70, 16): three tile rows over four ranks, so one rank owns nothing."""
     import torch.multiprocessing as mp
     rng = np.random.default_rng(H)
     full = rng.random((H, W), dtype=np.float32) + 0.25
     out = str(tmp_path / "final.npy")
-    mp.spawn(_worker, args=(2, _free_port(), H, W, full, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), H, W, full, out), nprocs=world, join=True)
     np.testing.assert_array_equal(np.load(out), full)
 
 
