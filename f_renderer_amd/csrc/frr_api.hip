@@ -223,26 +223,22 @@ template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks
     }
 }
 
-// Shape of the tile kernel's workgroups for `grid` tiles: NW waves per tile and the waves per SIMD its registers are
-// budgeted for.  Candidates (NW, workgroups resident per CU): (3, 8) (4, 8) (4, 6) (6, 4) (8, 3) (16, 1); a tile takes
-// about 1/NW of the time with NW waves, so the cost of a launch is rounds(grid / resident) / NW and the shape that
-// minimises it wins (ties: fewer, wider workgroups -- shorter chains).  256 CUs.
+// Shape of the tile kernel's workgroups for `grid` tiles: NW waves per tile (and the waves per SIMD its registers are
+// budgeted for).  Measured on the 1080p / 4096^2 / 4K frames (profiles/, tools/exp_shapes.py): a CU is issue-bound with
+// six 4-wave workgroups, so budgeting registers for eight buys nothing; wider workgroups shorten a tile's chain and win
+// when the tiles do not fill the chip (a partitioned rank, a small window); three waves per tile win when there are
+// many lightly loaded tiles (about 120 records each on the 4096^2 frame: four waves would cull 30 records apiece).
 struct SpanShape { int nw, occ; };
-SpanShape span_shape(const frr_ctx *c, uint32_t grid)
+SpanShape span_shape(const frr_ctx *c, uint32_t grid, uint64_t ntris)
 {
-    struct Cand { int nw, occ, per_cu; };
-    static const Cand cands[] = {{16, 4, 1}, {8, 6, 3}, {6, 6, 4}, {4, 8, 8}, {4, 6, 6}, {3, 6, 8}};
-    SpanShape best = {4, 6};
-    double best_cost = 1e30;
-    for (const Cand &k : cands) {
-        if (c->raster_nw && k.nw != c->raster_nw) continue;
-        if (c->raster_occ && k.occ != c->raster_occ) continue;
-        const uint32_t resident = 256u * (uint32_t)k.per_cu;
-        const double rounds = (double)((grid + resident - 1) / resident);
-        const double cost = rounds / (double)k.nw;
-        if (cost < best_cost - 1e-12) { best_cost = cost; best = {k.nw, k.occ}; }
-    }
-    return best;
+    static const SpanShape all[] = {{16, 4}, {8, 6}, {6, 6}, {4, 8}, {4, 6}, {3, 6}};
+    if (c->raster_nw || c->raster_occ)                   // FRR_RASTER_NW / FRR_RASTER_OCC (tests, tools)
+        for (const SpanShape &k : all)
+            if ((!c->raster_nw || k.nw == c->raster_nw) && (!c->raster_occ || k.occ == c->raster_occ)) return k;
+    if (grid <= 256u) return {16, 4};
+    if (grid <= 768u) return {8, 6};
+    if (grid > 1536u && ntris * 2u <= 192ull * grid) return {3, 6};
+    return {4, 6};
 }
 
 template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uint32_t grid, const SpanShape sh)
@@ -674,6 +670,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     a.x0 = x0; a.x1 = x1; a.y0 = y0; a.y1 = y1; a.win_w = (int)ww; a.win_h = (int)wh;
     a.cstride = (int)c->W; a.dstride = x1;
     a.tiles_x = (int)((ww + TILE - 1) / TILE); a.tiles_y = (int)((wh + TILE - 1) / TILE);
+    a.tiles_x_magic = 0u; // set below once the grid is known (exact only for block indices and tile counts < 2^16)
     a.rank = c->rank; a.world = c->world;
     a.rpr = (c->part_blocked && c->world > 1) ? std::max(1, (a.tiles_y + c->world - 1) / c->world) : 0;
     a.recs = c->recs; a.vary = c->vary; a.pbox = c->pbox;
@@ -700,7 +697,10 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     const int owned_rows = a.rpr > 0 ? std::max(0, std::min(a.tiles_y, (a.rank + 1) * a.rpr) - a.rank * a.rpr)
                                      : (a.tiles_y > a.rank ? (a.tiles_y - a.rank + a.world - 1) / a.world : 0);
     const uint32_t grid = (uint32_t)a.tiles_x * owned_rows;
-    const SpanShape sh = span_shape(c, grid);
+#ifndef FRR_NO_MAGIC
+    if (a.tiles_x >= 2 && a.tiles_x < 65536 && grid < 65536u) a.tiles_x_magic = (uint32_t)(0x100000000ull / (uint64_t)a.tiles_x + 1ull);
+#endif
+    const SpanShape sh = span_shape(c, grid, c->geom_ntris);
     if (ntiles <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep) {
         // segmented LDS multi-split (one launch, no per-entry global atomics): G chunk workgroups, ~3K triangles each
         // (small meshes: one triangle per thread, so that the launch is not three workgroups doing all the work)

@@ -105,6 +105,7 @@ struct RasterArgs {
     int32_t win_w, win_h;             // x1-x0, y1-y0
     int32_t cstride, dstride;         // colour row stride (fb.width), depth row stride (= x1, :362)
     int32_t tiles_x, tiles_y;
+    uint32_t tiles_x_magic;           // 2^32 / tiles_x + 1: block index -> tile row by one multiplication (0: plain division)
     int32_t rank, world;              // tile-row ownership: ty % world == rank (interleaved), or ...
     int32_t rpr;                      // ... rpr > 0: blocked, rank owns tile rows [rank*rpr, (rank+1)*rpr)
     const RasterRec *recs;

@@ -38,8 +38,10 @@ __device__ __forceinline__ TileCtx tile_ctx(const RasterArgs &a)
 {
     TileCtx c;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx = bid % a.tiles_x;
-    const int ty = a.rpr > 0 ? a.rank * a.rpr + bid / a.tiles_x : a.rank + (bid / a.tiles_x) * a.world;
+    // bid / tiles_x by multiplication (scalar unit): exact for bid, tiles_x < 2^16 (tiles_x_magic = 2^32 / tiles_x + 1; 0: divide)
+    const int trow = a.tiles_x_magic ? (int)__builtin_amdgcn_readfirstlane((int)__umulhi((uint32_t)bid, a.tiles_x_magic)) : bid / a.tiles_x;
+    const int tx = bid - trow * a.tiles_x;
+    const int ty = a.rpr > 0 ? a.rank * a.rpr + trow : a.rank + trow * a.world;
     c.tile = ty * a.tiles_x + tx;
     c.lx0 = tx * TILE; c.ly0 = ty * TILE;
     c.tw = min(TILE, a.win_w - c.lx0); c.th = min(TILE, a.win_h - c.ly0);
@@ -58,6 +60,15 @@ __device__ __forceinline__ TileCtx tile_ctx(const RasterArgs &a)
 __device__ __forceinline__ void tile_load_keys(const RasterArgs &a, const TileCtx &c, unsigned long long *s_key,
                                                unsigned long long oob = 0ull)
 {
+#ifndef FRR_NO_FASTKEYS
+    if (a.fused_clear && c.tw == TILE && c.th == TILE) {
+        // a full tile of a draw that carries the frame's clear: one constant, 32 bytes per lane and store
+        const uint32_t k = zkey(a.clear_depth);
+        uint4 *p = reinterpret_cast<uint4 *>(s_key);
+        for (int i = threadIdx.x; i < TILE_PX / 2; i += (int)blockDim.x) p[i] = make_uint4(0u, k, 0u, k);
+        return;
+    }
+#endif
     for (int i = threadIdx.x; i < TILE_PX; i += (int)blockDim.x) {
         const int x = i & (TILE - 1), y = i >> 5;
         unsigned long long k = oob;
@@ -132,6 +143,58 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
             const uint32_t q = quantize_u8(col[0]) | (quantize_u8(col[1]) << 8) | (quantize_u8(col[2]) << 16) |
                                (quantize_u8(col[3]) << 24);                     // :7-14
             reinterpret_cast<uint32_t *>(a.color)[(size_t)(c.ly0 + y) * a.cstride + (c.lx0 + x)] = q; // :381,:496-503
+        }
+    }
+}
+
+// Depth-only resolve, four pixels of a row per lane: 32 bytes of keys in, 16-byte stores of depth / ids (/ the clear
+// colour) out -- every row of the tile leaves as one full 128-byte line per target.  Rows whose addresses are not
+// 16-byte aligned (odd strides, caller-bound targets), partial tiles and -- when the draw does not carry the clear --
+// groups with a pixel nobody won take scalar stores; keys that merge -0.0 / NaN (see tile_resolve) are re-evaluated.
+__device__ __forceinline__ void tile_resolve_depth4(const RasterArgs &a, const TileCtx &c, const unsigned long long *s_key)
+{
+    const uint32_t tri_base = a.cnt->tri_base;
+    const uint32_t *gidx = a.cnt->gidx; // dense-owned draws: slot -> emission index
+    const bool fused = a.fused_clear != 0;
+    for (int g = threadIdx.x; g < TILE_PX / 4; g += (int)blockDim.x) {
+        const int y = g >> 3, x = (g & 7) * 4;
+        if (y >= c.th || x >= c.tw) continue;
+        const uint4 k01 = reinterpret_cast<const uint4 *>(s_key)[2 * g], k23 = reinterpret_cast<const uint4 *>(s_key)[2 * g + 1];
+        const uint32_t id[4] = {k01.x, k01.z, k23.x, k23.z}, zk[4] = {k01.y, k01.w, k23.y, k23.w};
+        uint32_t dv[4], iv[4];
+        bool won[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            won[i] = id[i] != 0u && x + i < c.tw;      // (pixels of a partial tile beyond the window hold all-ones keys)
+            float dz = zkey_decode(zk[i]);
+            if (won[i] && !(dz != 0.0f && dz == dz)) { // -0.0 merged with +0.0, or NaN: the reference arithmetic decides
+                const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + (id[i] - 1u));
+                const uint4 q1 = rp[1], q2 = rp[2], q3 = rp[3];
+                dz = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y), u2f(q3.z),
+                               c.ax0 + x + i, c.ay0 + y).rhw;
+            }
+            dv[i] = won[i] ? f2u(dz) : f2u(a.clear_depth);                                         // :366
+            iv[i] = won[i] ? tri_base + (gidx ? gidx[id[i] - 1u] : id[i] - 1u) : ~0u;
+        }
+        const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
+        const size_t ci = (size_t)(c.ly0 + y) * a.cstride + (c.lx0 + x);
+        const bool all_in = x + 4 <= c.tw;
+        const bool all_write = fused || (won[0] && won[1] && won[2] && won[3]);
+        const bool al = (((uintptr_t)(a.depth + di) | (uintptr_t)(a.tri_id + di)) & 15u) == 0u;
+        if (all_in && all_write && al) {
+            *reinterpret_cast<uint4 *>(a.depth + di) = make_uint4(dv[0], dv[1], dv[2], dv[3]);
+            *reinterpret_cast<uint4 *>(a.tri_id + di) = make_uint4(iv[0], iv[1], iv[2], iv[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (x + i < c.tw && (fused || won[i])) { reinterpret_cast<uint32_t *>(a.depth)[di + i] = dv[i]; a.tri_id[di + i] = iv[i]; }
+        }
+        if (fused) { // depth-only draws leave the colour target at the clear colour
+            uint32_t *cp = reinterpret_cast<uint32_t *>(a.color) + ci;
+            if (all_in && (((uintptr_t)cp) & 15u) == 0u) *reinterpret_cast<uint4 *>(cp) = make_uint4(a.clear_rgba, a.clear_rgba, a.clear_rgba, a.clear_rgba);
+            else
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (x + i < c.tw) cp[i] = a.clear_rgba;
         }
     }
 }
@@ -220,6 +283,10 @@ constexpr int SPAN_BATCH = 32;  // triangles per wavefront batch (staging sized 
 #define FRR_SPAN_CULL 32
 #endif
 constexpr int SPAN_CULL = FRR_SPAN_CULL; // bin entries culled per step (<= 64): smaller = fresher z minima, more steps
+#ifndef FRR_SPAN_AQ_MIN
+#define FRR_SPAN_AQ_MIN 1
+#endif
+constexpr int SPAN_AQ_MIN = FRR_SPAN_AQ_MIN; // survivors a wave collects before it rasterizes them (1: after every cull step)
 
 // wave64 inclusive prefix sum on the DPP network (row_shr within 16-lane rows, then row broadcasts)
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x)
@@ -262,26 +329,28 @@ __device__ __forceinline__ void seg_advance(uint32_t h_lo, uint32_t h_hi, int &b
     base += __popc(h_lo) + __popc(h_hi);
 }
 
-struct alignas(16) TriI {     // per-triangle integers staged for the span phase
-    int32_t e01, e12, e20;    // edge values at the bbox-in-tile origin
+// per-triangle integers and reciprocals staged for the span phase (48 bytes)
+struct alignas(16) SpanTri {
+    int32_t n01, n12, n20;     // (thr + 1) - E at the bbox-in-tile origin, thr = -1 for top-left edges else 0
+    uint32_t zub;              // zkey of an upper bound of rhw over the triangle
     uint32_t ab01, ab12, ab20; // A (low 16, signed) | B (high 16, signed)
-    uint32_t misc;            // bx0l:5 | by0l:5 <<5 | bw:6 <<10 | bias bits <<16
-    uint32_t zub;             // zkey of an upper bound of rhw over the triangle
+    uint32_t misc;             // bx0l:5 | by0l:5 <<5 | bw:6 <<10
+    float r01, r12, r20, pad;  // v_rcp_f32 of |A| per edge (0 for A == 0)
 };
 
-// dx in [lo,hi) with  Er + A*dx > thr  (thr in {-1,0}); exact floor division, see DESIGN.md
-__device__ __forceinline__ void edge_bound(int Er, int A, int thr, int &lo, int &hi)
+// edge_bound with the reciprocal of |A| supplied: dx in [lo,hi) with A*dx >= N
+__device__ __forceinline__ void edge_bound_pre(int N, int A, float rD, int &lo, int &hi)
 {
-    const int N = (thr + 1) - Er; // need A*dx >= N
-    if (A == 0) { if (N > 0) hi = 0; return; }
     const int D = A > 0 ? A : -A;
     const int M = A > 0 ? N + D - 1 : -N;           // A>0: dx >= ceil(N/A) = floor(M/D); A<0: dx <= floor(M/D)
-    float qf = (float)M * __builtin_amdgcn_rcpf((float)D);
+    float qf = (float)M * rD;
     qf = fminf(fmaxf(qf, -2.0f), 40.0f);            // only quotients in [0, 32] matter
     int q = (int)qf;
     const int r = M - __mul24(q, D);
     q += (r < 0) ? -1 : ((r >= D) ? 1 : 0);         // one correction step makes the in-range quotient exact
-    if (A > 0) lo = max(lo, q); else hi = min(hi, q + 1);
+    if (A > 0) lo = max(lo, q);
+    else if (A < 0) hi = min(hi, q + 1);
+    else if (N > 0) hi = 0;
 }
 
 // Hierarchical z: s_hiz[row*4 + seg] = min over the 8 pixels of (row, seg) of the depth part of the
@@ -293,26 +362,36 @@ constexpr int DIRECT_MAX = 256;  // records of a tile that are culled straight f
 constexpr int DIRECT_STEPS = 2;  // ... in this many steps per wave (at least DIRECT_MIN lanes each)
 constexpr int DIRECT_MIN = 4;
 constexpr int HZ_SEG = 0, HZ_BLK = 128, HZ_QUAD = 144, HZ_C4 = 148, HZ_SIZE = 404;
+// lane ^ 1 and lane ^ 2 inside each quad of lanes, on the DPP network (no LDS round trip)
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); } // quad_perm [1,0,3,2]
+__device__ __forceinline__ uint32_t dpp_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); } // quad_perm [2,3,0,1]
+
 __device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uint32_t *hz, int lane)
 {
-    // consecutive lanes read consecutive 16-byte chunks (2 keys): conflict-free; 4 lanes = one segment
+    // consecutive lanes read consecutive 16-byte chunks (2 keys): conflict-free; 4 lanes = one segment.
+    // All eight reads are issued before anything is written (the compiler must not assume hz and the keys are disjoint)
     const uint4 *p = reinterpret_cast<const uint4 *>(s_key);
+    uint32_t m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const uint4 v = p[64 * k + lane]; m[k] = min(v.y, v.w); }
+    uint32_t c4[8], sg[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const uint4 v = p[64 * k + lane];
-        uint32_t m = min(v.y, v.w);
-        m = min(m, (uint32_t)__shfl_xor((int)m, 1));
-        if ((lane & 1) == 0) hz[HZ_C4 + 32 * k + (lane >> 1)] = m;
-        m = min(m, (uint32_t)__shfl_xor((int)m, 2));
-        if ((lane & 3) == 0) hz[HZ_SEG + 16 * k + (lane >> 2)] = m;
+        c4[k] = min(m[k], dpp_xor1(m[k]));      // 4-pixel cell: lanes 2i, 2i+1
+        sg[k] = min(c4[k], dpp_xor2(c4[k]));    // 8-pixel segment: lanes 4i .. 4i+3
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if ((lane & 1) == 0) hz[HZ_C4 + 32 * k + (lane >> 1)] = c4[k];
+        if ((lane & 3) == 0) hz[HZ_SEG + 16 * k + (lane >> 2)] = sg[k];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane < 16) {                       // 8x8 blocks: 8 rows of one segment column
         const int by = lane >> 2, bx = lane & 3;
-        uint32_t m = 0xFFFFFFFFu;
+        uint32_t mm = 0xFFFFFFFFu;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) m = min(m, hz[HZ_SEG + (by * 8 + r) * 4 + bx]);
-        hz[HZ_BLK + lane] = m;
+        for (int r = 0; r < 8; ++r) mm = min(mm, hz[HZ_SEG + (by * 8 + r) * 4 + bx]);
+        hz[HZ_BLK + lane] = mm;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane < 4) {                        // 16x16 quads: 2x2 blocks
@@ -329,20 +408,20 @@ __device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uin
 // LDS is carved by hand from one buffer so that what only the pre-pass needs (segment tables, the exchange buffer
 // of the direct path) can share its bytes with what only the main loop needs (per-wave staging and queues):
 //   [keys 8 KiB][union { main-loop staging | pre-pass tables }][hi-z][buckets][scalars][u8 table (textured only)]
-// With B = 16 staged triangles per wave and NW = 4 that is 18.0 KiB (19.0 textured): eight workgroups per CU.
+// With B = 16 staged triangles per wave and NW = 4 that is 18.0 KiB (19.0 textured): eight workgroups per CU;
+// with B = 32 it is 23.9 KiB: six.
 template <int NW, int B> struct SpanLds {
     static constexpr int KEY = 0;
     static constexpr int U0 = KEY + TILE_PX * 8;
     // main loop, per wave
-    static constexpr int TI = U0;                       // TriI[NW][B]
-    static constexpr int FA = TI + NW * B * 32;         // float4[NW][B]  s0x s0y s1x s1y
+    static constexpr int TRI = U0;                      // SpanTri[NW][B]
+    static constexpr int FA = TRI + NW * B * 48;        // float4[NW][B]  s0x s0y s1x s1y
     static constexpr int FB = FA + NW * B * 16;         // float4[NW][B]  s2x s2y rhw0 rhw1
     static constexpr int FC = FB + NW * B * 16;         // float2[NW][B]  rhw2, bit pattern of (triangle index + 1)
     static constexpr int HROW = FC + NW * B * 8;        // u64[NW][B/2]   heads of (triangle -> rows): B*32 bits
     static constexpr int HFRAG = HROW + NW * (B / 2) * 8; // u64[NW][32]  heads of (span -> fragments): 64*32 bits
     static constexpr int Q = HFRAG + NW * 32 * 8;       // u32[NW][64]    compacted span descriptors
-    static constexpr int AQ = Q + NW * 64 * 4;          // u32[NW][64]    per wave: triangles that survived phase 1a
-    static constexpr int M_END = AQ + NW * 64 * 4;
+    static constexpr int M_END = Q + NW * 64 * 4;
     // pre-pass (aliases the main-loop region; a barrier separates the two uses)
     static constexpr int SEGPRE = U0;                   // u32[BIN_MAX_G + 1] entries of this tile before segment g
     static constexpr int SEGSRC = SEGPRE + ((BIN_MAX_G + 1 + 3) & ~3) * 4; // u32[BIN_MAX_G] where segment g starts in a.bins
@@ -359,19 +438,18 @@ template <int NW, int B> struct SpanLds {
 template <int K, int PS, bool COUNT, int NW, int OCC>
 __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevUniforms u, int win_safe)
 {
-    constexpr int B = (OCC >= 8 || NW <= 3) ? 16 : SPAN_BATCH; // staged triangles per wave (LDS budget of 8 workgroups per CU)
+    constexpr int B = (OCC >= 8 || NW <= 3 || NW >= 16) ? 16 : SPAN_BATCH; // staged triangles per wave (LDS budget: 8 workgroups per CU; 64 KiB of static LDS at NW = 16)
     constexpr bool TEXTURED = PS == FRR_PS_PHONG || PS == FRR_PS_BLINN;
     using L = SpanLds<NW, B>;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[L::bytes(TEXTURED)];
     unsigned long long *const s_key = reinterpret_cast<unsigned long long *>(s_raw + L::KEY);
-    TriI (*const s_ti)[B] = reinterpret_cast<TriI (*)[B]>(s_raw + L::TI);
+    SpanTri (*const s_tri)[B] = reinterpret_cast<SpanTri (*)[B]>(s_raw + L::TRI);
     float4 (*const s_fa)[B] = reinterpret_cast<float4 (*)[B]>(s_raw + L::FA);
     float4 (*const s_fb)[B] = reinterpret_cast<float4 (*)[B]>(s_raw + L::FB);
     float2 (*const s_fc)[B] = reinterpret_cast<float2 (*)[B]>(s_raw + L::FC);
     unsigned long long (*const s_hrow)[B / 2] = reinterpret_cast<unsigned long long (*)[B / 2]>(s_raw + L::HROW);
     unsigned long long (*const s_hfrag)[32] = reinterpret_cast<unsigned long long (*)[32]>(s_raw + L::HFRAG);
     uint32_t (*const s_q)[64] = reinterpret_cast<uint32_t (*)[64]>(s_raw + L::Q);
-    uint32_t (*const s_aq)[64] = reinterpret_cast<uint32_t (*)[64]>(s_raw + L::AQ);
     uint32_t *const s_segpre = reinterpret_cast<uint32_t *>(s_raw + L::SEGPRE);
     uint32_t *const s_segsrc = reinterpret_cast<uint32_t *>(s_raw + L::SEGSRC);
     uint4 *const s_exch = reinterpret_cast<uint4 *>(s_raw + L::EXCH);
@@ -525,129 +603,119 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
     uint32_t d_pre = 0, d_win = 0, d_rebuild = 0; // fragments a per-pixel zub test would skip; fragments that took the pixel; hi-z rebuilds
 #endif
 
-    int aq_n = 0;            // survivors waiting in this wave's queue (wave-uniform)
-    bool input_done = false;
+    // bin entries culled per step: every survivor of a step gets a staging slot (<= B per wave), and its fragments are
+    // resolved before the next step culls (fresh z minima: the early-z of the later, farther records lives on them)
+    constexpr int CULL = SPAN_CULL < B ? SPAN_CULL : B;
+    if (direct) { // (B can be smaller than half a wave)
+        const int nsteps = max(DIRECT_STEPS, (dcount + B - 1) / B);
+        dstep = max(min(DIRECT_MIN, B), (dcount + nsteps - 1) / nsteps);
+    }
     FRR_T(0);
 #ifdef FRR_DEBUG_COUNTERS
     d_rt1 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (;;) {
-        // ---- phase 1a: lane = bin entry, 64 per step.  bbox-in-tile + whole-triangle early-z on the
-        // 16-byte cull records only; survivors are queued, nothing else is touched for the rest. ----
-        if (!input_done && aq_n == 0) { // survivors are processed before more entries are culled (fresh z minima)
-            uint32_t e0 = 0;
-            bool have = true;
-            int dlo = 0;
-            if (direct) {
-                dlo = dpos;
-                dpos += dstep;
-                have = dlo < dcount;
-                if (dpos >= dcount) input_done = true;
-            } else {
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(&s_next, 1u);
-                b = __builtin_amdgcn_readfirstlane(b);
-                e0 = c.beg + b * (uint32_t)SPAN_CULL;
-                have = e0 < c.end;
-                if (!have) input_done = true;
-            }
-            if (have) {
-                // the minima are rebuilt only if some wave has resolved fragments since the last rebuild
-                // (a stale minimum is a lower one: still conservative)
-                if (__builtin_amdgcn_readfirstlane(s_dirty) != 0u) {
-                    FRR_T(1);
-                    if (lane == 0) s_dirty = 0u;
-                    hiz_rebuild(s_key, s_hz, lane);
-#ifdef FRR_DEBUG_COUNTERS
-                    ++d_rebuild;
-#endif
-                    FRR_T(2);
-                }
-                wave_lds_fence();
-                const bool valid = direct ? (dvalid && lane >= dlo && lane < dlo + dstep) : lane < (int)min((uint32_t)SPAN_CULL, c.end - e0);
-                const uint4 en = direct ? dent : (valid ? ents[e0 + lane] : make_uint4(0, 0, 0, 0));
-                const int mnx = (int)(short)(en.z & 0xFFFFu), mny = (int)(short)(en.z >> 16);
-                const int mxx = (int)(short)(en.w & 0xFFFFu), mxy = (int)(short)(en.w >> 16);
-                const int bx0 = max(clampi(mnx, a.x0, a.x1), c.ax0), bx1 = min(clampi(mxx, a.x0, a.x1), c.ax0 + c.tw);
-                const int by0 = max(clampi(mny, a.y0, a.y1), c.ay0), by1 = min(clampi(mxy, a.y0, a.y1), c.ay0 + c.th);
-                const bool nonempty = valid && bx1 > bx0 && by1 > by0;
-                // (the bbox saturates at +-32767, so out-of-range vertices show up here too)
-                const int amax = max(max(abs(mnx), abs(mxx)), max(abs(mny), abs(mxy)));
-                const bool safe = nonempty && win_safe && amax <= SPAN_SAFE;
-                bool alive = safe;
-                if (!COUNT && safe) {
-                    // against the 8x8 block minima when the bbox touches <= 2x2 blocks, else against the
-                    // 16x16 quad minima (a tile has 2x2 quads, so this always applies)
-                    const int gx0 = (bx0 - c.ax0) >> 3, gx1 = (bx1 - 1 - c.ax0) >> 3, gy0 = (by0 - c.ay0) >> 3, gy1 = (by1 - 1 - c.ay0) >> 3;
-                    const bool small = gx1 - gx0 <= 1 && gy1 - gy0 <= 1;
-                    const uint32_t *lv = s_hz + (small ? HZ_BLK : HZ_QUAD);
-                    const int sh = small ? 0 : 1, st = small ? 4 : 2;
-                    const int ix0 = gx0 >> sh, ix1 = gx1 >> sh, iy0 = gy0 >> sh, iy1 = gy1 >> sh;
-                    const uint32_t hm = min(min(lv[iy0 * st + ix0], lv[iy0 * st + ix1]), min(lv[iy1 * st + ix0], lv[iy1 * st + ix1]));
-                    alive = !(en.y < hm);
-                }
-#ifdef FRR_DEBUG_COUNTERS
-                d_tri += __popcll(__ballot(nonempty)); d_alive += __popcll(__ballot(alive));
-#endif
-                // triangles outside the span algebra's safe range: exact brute-force sweep, right away
-                unsigned long long um = __ballot(nonempty && !safe);
-                while (um) {
-                    const int src = __builtin_ctzll(um);
-                    um &= um - 1;
-                    const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)en.x, src);
-                    uint32_t ncv = 0;
-                    sweep_triangle(a, c, tu, lane, s_key, ncv, n_nan);
-                    n_cov += ncv;
-                }
-                const unsigned long long am = __ballot(alive);
-                const int arank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-                if (alive) s_aq[w][aq_n + arank] = en.x;
-                aq_n += __popcll(am);
-                wave_lds_fence();
-            }
+        // ---- phase 1: lane = bin entry, CULL per step.  bbox-in-tile + whole-triangle early-z on the 16-byte cull
+        // record; a survivor then fetches its 64-byte setup record and stages its edge data at its RANK among the
+        // survivors (lanes and ranks ascend together, so "the k-th head" below is staging slot k) ----
+        uint32_t e0 = 0;
+        int dlo = 0;
+        if (direct) {
+            dlo = dpos;
+            dpos += dstep;
+            if (dlo >= dcount) break;
+        } else {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(&s_next, 1u);
+            b = __builtin_amdgcn_readfirstlane(b);
+            e0 = c.beg + b * (uint32_t)CULL;
+            if (e0 >= c.end) break;
         }
+        // the minima are rebuilt only if some wave has resolved fragments since the last rebuild
+        // (a stale minimum is a lower one: still conservative)
+        if (__builtin_amdgcn_readfirstlane(s_dirty) != 0u) {
+            FRR_T(1);
+            if (lane == 0) s_dirty = 0u;
+            hiz_rebuild(s_key, s_hz, lane);
+#ifdef FRR_DEBUG_COUNTERS
+            ++d_rebuild;
+#endif
+            FRR_T(2);
+        }
+        wave_lds_fence();
+        const bool valid = direct ? (dvalid && lane >= dlo && lane < dlo + dstep) : lane < (int)min((uint32_t)CULL, c.end - e0);
+        const uint4 en = direct ? dent : (valid ? ents[e0 + lane] : make_uint4(0, 0, 0, 0));
+        const int mnx = (int)(short)(en.z & 0xFFFFu), mny = (int)(short)(en.z >> 16);
+        const int mxx = (int)(short)(en.w & 0xFFFFu), mxy = (int)(short)(en.w >> 16);
+        // clamped bbox (renderer.rs:285-298) in this tile: the i16 box is the saturated min/max of spi and the window
+        // lies inside the i16 range, so clamping it equals clamping the i32 values
+        const int bx0 = max(clampi(mnx, a.x0, a.x1), c.ax0), bx1 = min(clampi(mxx, a.x0, a.x1), c.ax0 + c.tw);
+        const int by0 = max(clampi(mny, a.y0, a.y1), c.ay0), by1 = min(clampi(mxy, a.y0, a.y1), c.ay0 + c.th);
+        const bool nonempty = valid && bx1 > bx0 && by1 > by0;
+        // (the bbox saturates at +-32767, so out-of-range vertices show up here too)
+        const int amax = max(max(abs(mnx), abs(mxx)), max(abs(mny), abs(mxy)));
+        const bool safe = nonempty && win_safe && amax <= SPAN_SAFE;
+        bool alive = safe;
+        if (!COUNT && safe) {
+            // against the 8x8 block minima when the bbox touches <= 2x2 blocks, else against the
+            // 16x16 quad minima (a tile has 2x2 quads, so this always applies)
+            const int gx0 = (bx0 - c.ax0) >> 3, gx1 = (bx1 - 1 - c.ax0) >> 3, gy0 = (by0 - c.ay0) >> 3, gy1 = (by1 - 1 - c.ay0) >> 3;
+            const bool small = gx1 - gx0 <= 1 && gy1 - gy0 <= 1;
+            const uint32_t *lv = s_hz + (small ? HZ_BLK : HZ_QUAD);
+            const int sh = small ? 0 : 1, st = small ? 4 : 2;
+            const int ix0 = gx0 >> sh, ix1 = gx1 >> sh, iy0 = gy0 >> sh, iy1 = gy1 >> sh;
+            const uint32_t hm = min(min(lv[iy0 * st + ix0], lv[iy0 * st + ix1]), min(lv[iy1 * st + ix0], lv[iy1 * st + ix1]));
+            alive = !(en.y < hm);
+        }
+#ifdef FRR_DEBUG_COUNTERS
+        d_tri += __popcll(__ballot(nonempty)); d_alive += __popcll(__ballot(alive));
+#endif
+        // triangles outside the span algebra's safe range: exact brute-force sweep, right away
+        unsigned long long um = __ballot(nonempty && !safe);
+        while (um) {
+            const int src = __builtin_ctzll(um);
+            um &= um - 1;
+            const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)en.x, src);
+            uint32_t ncv = 0;
+            sweep_triangle(a, c, tu, lane, s_key, ncv, n_nan);
+            n_cov += ncv;
+        }
+        const unsigned long long am = __ballot(alive);
         FRR_T(1);
-        if (aq_n == 0) { if (input_done) break; continue; }
-
-        // ---- phase 1b: lane = surviving triangle.  Record gather, edge coefficients, staging ----
-        const int nb = min(aq_n, B);
-        aq_n -= nb;
-        const bool valid = lane < nb;
-        const uint32_t t = valid ? s_aq[w][aq_n + lane] : 0u;
-        const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + t);
-        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
-        if (valid) { q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3]; }
-        const int p0x = (int)q0.x, p0y = (int)q0.y, p1x = (int)q0.z, p1y = (int)q0.w, p2x = (int)q1.x, p2y = (int)q1.y;
-        int bx0 = clampi(min(p0x, min(p1x, p2x)), a.x0, a.x1), bx1 = clampi(max(p0x, max(p1x, p2x)), a.x0, a.x1);
-        int by0 = clampi(min(p0y, min(p1y, p2y)), a.y0, a.y1), by1 = clampi(max(p0y, max(p1y, p2y)), a.y0, a.y1);
-        bx0 = max(bx0, c.ax0); bx1 = min(bx1, c.ax0 + c.tw);
-        by0 = max(by0, c.ay0); by1 = min(by1, c.ay0 + c.th);
-        const int bw = bx1 - bx0, bh = by1 - by0;
-        const float ar0 = fabsf(u2f(q3.x)), ar1 = fabsf(u2f(q3.y)), ar2 = fabsf(u2f(q3.z));
-        const float ub = fmaxf(fmaxf(ar0, ar1), ar2) * 1.000003814697265625f;
-        const uint32_t zub = (ar0 == ar0 && ar1 == ar1 && ar2 == ar2) ? zkey(ub) : 0xFFFFFFFFu;
-        const bool alive = valid; // every queued triangle is non-empty in this tile and in the safe range
-        const uint32_t rows = alive ? (uint32_t)bh : 0u;
+        if (am == 0ull) continue;
+        const int trank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+        const uint32_t rows = alive ? (uint32_t)(by1 - by0) : 0u;
         if (alive) {
-            // wrapping arithmetic spelled in u32; for `safe` triangles nothing wraps
-            const uint32_t A01 = 0u - (uint32_t)(p1y - p0y), B01 = (uint32_t)(p1x - p0x);
-            const uint32_t A12 = 0u - (uint32_t)(p2y - p1y), B12 = (uint32_t)(p2x - p1x);
-            const uint32_t A20 = 0u - (uint32_t)(p0y - p2y), B20 = (uint32_t)(p0x - p2x);
-            TriI ti;
-            ti.e01 = (int)(A01 * (uint32_t)(bx0 - p0x) + B01 * (uint32_t)(by0 - p0y));
-            ti.e12 = (int)(A12 * (uint32_t)(bx0 - p1x) + B12 * (uint32_t)(by0 - p1y));
-            ti.e20 = (int)(A20 * (uint32_t)(bx0 - p2x) + B20 * (uint32_t)(by0 - p2y));
-            ti.ab01 = (A01 & 0xFFFFu) | (B01 << 16);
-            ti.ab12 = (A12 & 0xFFFFu) | (B12 << 16);
-            ti.ab20 = (A20 & 0xFFFFu) | (B20 << 16);
-            ti.misc = (uint32_t)(bx0 - c.ax0) | ((uint32_t)(by0 - c.ay0) << 5) | ((uint32_t)bw << 10) | (((q3.w >> 1) & 7u) << 16);
-            ti.zub = zub;
-            s_ti[w][lane] = ti;
-            s_fa[w][lane] = make_float4(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y));
-            s_fb[w][lane] = make_float4(u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y));
-            s_fc[w][lane] = make_float2(u2f(q3.z), u2f(t + 1u));
+            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + en.x);
+            const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+            const int p0x = (int)q0.x, p0y = (int)q0.y, p1x = (int)q0.z, p1y = (int)q0.w, p2x = (int)q1.x, p2y = (int)q1.y;
+            // edge functions E = A*(cx - px) + B*(cy - py) (renderer.rs:329-331); nothing wraps for `safe` triangles
+            const int A01 = -(p1y - p0y), B01 = p1x - p0x;
+            const int A12 = -(p2y - p1y), B12 = p2x - p1x;
+            const int A20 = -(p0y - p2y), B20 = p0x - p2x;
+            const int e01 = A01 * (bx0 - p0x) + B01 * (by0 - p0y);   // at the bbox-in-tile origin
+            const int e12 = A12 * (bx0 - p1x) + B12 * (by0 - p1y);
+            const int e20 = A20 * (bx0 - p2x) + B20 * (by0 - p2y);
+            // accept E > thr, thr = -1 for top-left edges, else 0 (:333-341): a row needs A*dx >= (thr + 1 - E_row)
+            SpanTri t;
+            t.n01 = (int)((q3.w >> 1) & 1u) - e01;
+            t.n12 = (int)((q3.w >> 2) & 1u) - e12;
+            t.n20 = (int)((q3.w >> 3) & 1u) - e20;
+            t.zub = en.y;                        // zkey of an upper bound of rhw over the triangle (cull_zub)
+            t.ab01 = ((uint32_t)A01 & 0xFFFFu) | ((uint32_t)B01 << 16);
+            t.ab12 = ((uint32_t)A12 & 0xFFFFu) | ((uint32_t)B12 << 16);
+            t.ab20 = ((uint32_t)A20 & 0xFFFFu) | ((uint32_t)B20 << 16);
+            t.misc = (uint32_t)(bx0 - c.ax0) | ((uint32_t)(by0 - c.ay0) << 5) | ((uint32_t)(bx1 - bx0) << 10);
+            t.r01 = A01 ? __builtin_amdgcn_rcpf((float)abs(A01)) : 0.0f;   // the span quotients' 1-ulp reciprocals, once per triangle
+            t.r12 = A12 ? __builtin_amdgcn_rcpf((float)abs(A12)) : 0.0f;
+            t.r20 = A20 ? __builtin_amdgcn_rcpf((float)abs(A20)) : 0.0f;
+            t.pad = 0.0f;
+            s_tri[w][trank] = t;
+            s_fa[w][trank] = make_float4(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y));
+            s_fb[w][trank] = make_float4(u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y));
+            s_fc[w][trank] = make_float2(u2f(q3.z), u2f(en.x + 1u));
         }
-        // rows of all triangles laid end to end: heads mark where each triangle's rows start
+        // rows of all survivors laid end to end: heads mark where each triangle's rows start
         const uint32_t rincl = wave_incl_scan_dpp(rows);
         const int R = (int)__builtin_amdgcn_readlane((int)rincl, 63);
         if (lane < B / 2) s_hrow[w][lane] = 0ull;
@@ -656,38 +724,32 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             const uint32_t st = rincl - rows;
             atomicOr(reinterpret_cast<uint32_t *>(&s_hrow[w][0]) + (st >> 5), 1u << (st & 31));
         }
-        // heads are counted, so triangles are addressed by rank among the safe ones: rank -> lane
-        const unsigned long long safe_mask = __ballot(rows != 0u);
-        const int trank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(safe_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)safe_mask, 0u));
-        if (rows) s_q[w][trank] = (uint32_t)lane;
         wave_lds_fence();
-        const uint32_t tri_of_rank = s_q[w][lane & (B - 1)];
+        const unsigned long long hrow_mine = s_hrow[w][lane & (B / 2 - 1)]; // lane i keeps the heads of row window i
         wave_lds_fence();
 
         int jbase = 0, jcarry = 0; // heads seen in earlier row windows; rows of the open triangle already done
         FRR_T(3);
         for (int r0 = 0; r0 < R; r0 += 64) {
             // ---- phase 2: lane = (triangle, row).  Exact covered span of that row. ----
-            const unsigned long long hrow = s_hrow[w][r0 >> 6];
-            const uint32_t h_lo = __builtin_amdgcn_readfirstlane((uint32_t)hrow);
-            const uint32_t h_hi = __builtin_amdgcn_readfirstlane((uint32_t)(hrow >> 32));
+            const uint32_t h_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hrow_mine, r0 >> 6);
+            const uint32_t h_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hrow_mine >> 32), r0 >> 6);
             const SegPos sp = seg_locate(h_lo, h_hi, le_lo, le_hi, lane, jcarry);
             const bool ractive = r0 + lane < R;
-            const int jr = jbase + sp.k - 1;                                   // rank of the triangle
-            const int j = __shfl((int)tri_of_rank, ractive ? jr : 0);          // its staging slot (lane of phase 1)
+            const int j = jbase + sp.k - 1;                                    // staging slot = rank of the triangle
             int len = 0, xl = 0, yl = 0;
             uint32_t zu = 0xFFFFFFFFu;
             if (ractive) {
-                const TriI ti = s_ti[w][j];
+                const SpanTri ti = s_tri[w][j];
                 const int row = sp.off;
                 const int bwj = (int)((ti.misc >> 10) & 63u);
                 const int A01 = (int)(ti.ab01 << 16) >> 16, B01 = (int)ti.ab01 >> 16;
                 const int A12 = (int)(ti.ab12 << 16) >> 16, B12 = (int)ti.ab12 >> 16;
                 const int A20 = (int)(ti.ab20 << 16) >> 16, B20 = (int)ti.ab20 >> 16;
                 int lo = 0, hi = bwj;
-                edge_bound(ti.e01 + __mul24(B01, row), A01, (ti.misc & (1u << 16)) ? 0 : -1, lo, hi);
-                edge_bound(ti.e12 + __mul24(B12, row), A12, (ti.misc & (1u << 17)) ? 0 : -1, lo, hi);
-                edge_bound(ti.e20 + __mul24(B20, row), A20, (ti.misc & (1u << 18)) ? 0 : -1, lo, hi);
+                edge_bound_pre(ti.n01 - __mul24(B01, row), A01, ti.r01, lo, hi);
+                edge_bound_pre(ti.n12 - __mul24(B12, row), A12, ti.r12, lo, hi);
+                edge_bound_pre(ti.n20 - __mul24(B20, row), A20, ti.r20, lo, hi);
                 len = max(hi - lo, 0);
                 xl = (int)(ti.misc & 31u) + lo;
                 yl = (int)((ti.misc >> 5) & 31u) + row;
@@ -734,6 +796,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
                 s_q[w][srank] = (uint32_t)j | ((uint32_t)yl << 6) | ((uint32_t)xl << 11); // span descriptor
             }
             wave_lds_fence();
+            const unsigned long long hfrag_mine = s_hfrag[w][lane & 31]; // lane i keeps the heads of fragment window i
 
             // ---- phase 3: lane = fragment.  Barycentrics, rhw, z key, LDS atomic max ----
 #ifdef FRR_DEBUG_COUNTERS
@@ -742,9 +805,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             int qbase = 0, qcarry = 0;
             FRR_T(4);
             for (int f0 = 0; f0 < F; f0 += 64) {
-                const unsigned long long hf = s_hfrag[w][f0 >> 6];
-                const uint32_t g_lo = __builtin_amdgcn_readfirstlane((uint32_t)hf);
-                const uint32_t g_hi = __builtin_amdgcn_readfirstlane((uint32_t)(hf >> 32));
+                const uint32_t g_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hfrag_mine, f0 >> 6);
+                const uint32_t g_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hfrag_mine >> 32), f0 >> 6);
                 const SegPos fp = seg_locate(g_lo, g_hi, le_lo, le_hi, lane, qcarry);
                 if (f0 + lane < F) {
                     const uint32_t d = s_q[w][qbase + fp.k - 1];
@@ -757,7 +819,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
                         const unsigned long long key = ((unsigned long long)zkey(f.rhw) << 32) | (unsigned long long)f2u(fc.y);
 #ifdef FRR_DEBUG_COUNTERS
                         const unsigned long long old = atomicMax(&s_key[y * TILE + x], key);
-                        d_pre += __popcll(__ballot(s_ti[w][sj].zub < (uint32_t)(old >> 32)));
+                        d_pre += __popcll(__ballot(s_tri[w][sj].zub < (uint32_t)(old >> 32)));
                         d_win += __popcll(__ballot(key > old));
 #else
                         atomicMax(&s_key[y * TILE + x], key);
@@ -771,8 +833,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             FRR_T(5);
         }
 
-        wave_lds_fence(); // staging is rewritten by the next batch
+        wave_lds_fence(); // staging is rewritten by the next step
     }
+    FRR_T(1);
     if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
 #ifdef FRR_DEBUG_COUNTERS
     d_rt2 = __builtin_amdgcn_s_memrealtime();
@@ -787,6 +850,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
     if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
     __syncthreads();
     FRR_T(6);
+#ifndef FRR_NO_DEPTH4
+    if constexpr (PS == FRR_PS_DEPTH) tile_resolve_depth4(a, c, s_key);
+    else
+#endif
     tile_resolve<K, PS>(a, u, c, s_key, TEXTURED ? s_u8 : nullptr);
 #ifdef FRR_DEBUG_COUNTERS
     FRR_T(7);
