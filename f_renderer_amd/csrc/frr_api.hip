@@ -14,9 +14,9 @@ using namespace frr;
 
 namespace {
 
-enum KernelId { KID_CLEAR, KID_GEOM_COUNT, KID_SCAN_BLOCKS, KID_GEOM_EMIT, KID_BIN_COUNT,
+enum KernelId { KID_CLEAR, KID_GEOM, KID_GEOM_SCAN, KID_GEOM_UNUSED, KID_BIN_COUNT,
                 KID_TILE_SCAN, KID_BIN_FILL, KID_RASTER, KID_BIN_SEG, KID_COUNT };
-const char *const kKernelNames[KID_COUNT] = {"k_clear", "k_geom_count", "k_scan_blocks", "k_geom_emit",
+const char *const kKernelNames[KID_COUNT] = {"k_clear", "k_geom", "k_geom_scan", "k_unused",
                                              "k_bin_count", "k_tile_scan", "k_bin_fill",
                                              "k_raster", "k_bin_seg"};
 
@@ -43,18 +43,18 @@ struct frr_ctx {
     float *depth = nullptr, *own_depth = nullptr;
     uint32_t *tri_id = nullptr, *own_tri_id = nullptr;
     Counters *cnt = nullptr;
-    // geometry workspace
-    uint32_t *block_sums = nullptr; size_t block_sums_cap = 0;
-    uint32_t *group_sums = nullptr; size_t group_sums_cap = 0; // four slots of 128 padded group counters (GeomArgs)
-    uint32_t *block_sums_g = nullptr; size_t block_sums_g_cap = 0; // dense-owned draws: per-block sums over ALL triangles
-    uint32_t *gidx = nullptr; size_t gidx_cap = 0;                 // dense-owned draws: emission index of each setup slot
-    uint2 *fast_list = nullptr; size_t fast_list_cap = 0;         // dense-owned draws: per count block, its owned unclipped triangles
-    uint32_t *fast_count = nullptr; size_t fast_count_cap = 0;
+    // geometry workspace (slots and order keys: frr_device.h)
+    uint32_t *block_sums = nullptr; size_t block_sums_cap = 0; // per 256-triangle block: triangles emitted; scanned in place
+    uint32_t *tinfo = nullptr; size_t tinfo_cap = 0;           // per input: fan size | emission offset in its block
+    uint32_t *fanbase = nullptr; size_t fanbase_cap = 0;       // per clipped input: first fan slot
+    uint32_t *fan_okey = nullptr; size_t fan_okey_cap = 0;     // per fan slot: order key within the draw
     struct GeomFilter { bool active; int32_t y0, y1; int rank, world; bool blocked; };
     GeomFilter geom_filter = {false, 0, 0, 0, 1, false}; // tile-row ownership filter the latest setup list was built with (frr_draw on a partitioned ctx)
-    bool geom_no_dense = false; // FRR_GEOM=nodense: partitioned draws keep a slot for every triangle (tests)
-    int geom_slot = 0;         // group_sums slot of the latest draw (alternates)
-    uint4 *clip_list = nullptr; size_t clip_list_cap = 0;     // clipped triangles of the current draw (k_geom_count -> k_geom_emit)
+    int geom_slot = 0;         // Counters::fan_cursor slot of the latest draw (alternates per draw)
+    uint32_t geom_fan_cap = 0; // fan capacity the latest draw was launched with
+    uint32_t geom_nblocks = 0;
+    bool scan_pending = false; // the latest draw's block sums are not scanned yet (geom_scan: by the binning launch, or k_geom_scan)
+    size_t fan_hint = 0;       // fan capacity asked for by a draw that overflowed
     int bin_g = 0;             // FRR_BIN_G: override the number of binning chunks (dev)
     uint32_t ent_slot_override = 0; // FRR_ENT_SLOT: per-tile slot of bins2 in records (tests of the overflow arena)
     // frr_clear is deferred: the first full-window draw of the span kernel performs it inside the tile kernel
@@ -70,8 +70,7 @@ struct frr_ctx {
     int bin_slot = 0;          // Counters::seg_total / ent_cursor slot of the latest draw (alternates)
     bool bin_atomics = false;  // FRR_BIN=atomics: force the global-atomic binning fallback (tests)
     size_t bin_cap_init = 0;   // FRR_BIN_CAP: initial bin capacity in entries (tests of the overflow path)
-    bool geom_force_scan = false; // FRR_GEOM=scan: always launch k_scan_blocks (the path used beyond 8192 blocks)
-    RasterRec *recs = nullptr; size_t setup_cap = 0; size_t setup_hint = 0;
+    RasterRec *recs = nullptr; size_t setup_cap = 0;            // [input triangles + fan capacity]
     float *vary = nullptr; size_t vary_cap = 0; // floats
     uint4 *pbox = nullptr; size_t pbox_cap = 0;
     // binning workspace
@@ -205,7 +204,7 @@ int check_frame_counters(frr_ctx *c, Counters *host)
             if (ensure(c, c->bins, c->bin_cap, need) != FRR_OK) return FRR_ERR_NOMEM;
             if (ensure(c, c->bins2, c->bin2_cap, need) != FRR_OK) return FRR_ERR_NOMEM;
         }
-        if (h.overflow & 1u) c->setup_hint = (size_t)h.need_setup + h.need_setup / 8 + 1024;
+        if (h.overflow & 1u) c->fan_hint = (size_t)h.need_fans + h.need_fans / 8 + 1024;
         return fail(c, FRR_ERR_CAPACITY, "device work list overflowed; capacity grown, re-issue the frame");
     }
     return FRR_OK;
@@ -213,14 +212,18 @@ int check_frame_counters(frr_ctx *c, Counters *host)
 
 template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks)
 {
-    g.selfsum = nblocks <= 8192 && !c->geom_force_scan; // emit blocks then derive their prefix from the two-level sums themselves
-    { ProfScope p(c, KID_GEOM_COUNT); hipLaunchKernelGGL(k_geom_count<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
-    if (g.selfsum) {
-        { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 2>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
-    } else {
-        { ProfScope p(c, KID_SCAN_BLOCKS); hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, g.block_sums, nblocks, g.cap, g.ntris, g.cnt, g.reset_frame); }
-        { ProfScope p(c, KID_GEOM_EMIT); hipLaunchKernelGGL((k_geom_emit<VS, 0>), dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni); }
-    }
+    ProfScope p(c, KID_GEOM);
+    hipLaunchKernelGGL(k_geom_single<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni);
+}
+
+// the latest draw's block sums -> prefix (+ n_emit, the fan-capacity flag), if no binning launch has done it
+int scan_now(frr_ctx *c)
+{
+    if (!c->scan_pending) return FRR_OK;
+    { ProfScope p(c, KID_GEOM_SCAN); hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, c->stream, c->block_sums, c->geom_nblocks, c->cnt, c->geom_slot, c->geom_fan_cap); }
+    HIP_TRY(c, hipGetLastError());
+    c->scan_pending = false;
+    return FRR_OK;
 }
 
 // Shape of the tile kernel's workgroups for `grid` tiles: NW waves per tile (and the waves per SIMD its registers are
@@ -311,7 +314,6 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     { const char *e = getenv("FRR_RASTER"); c->raster_sweep = e && strcmp(e, "sweep") == 0; }
     { const char *e = getenv("FRR_RASTER_NW"); const int v = e ? atoi(e) : 0; c->raster_nw = (v == 3 || v == 4 || v == 6 || v == 8 || v == 16) ? v : 0; }
     { const char *e = getenv("FRR_RASTER_OCC"); const int v = e ? atoi(e) : 0; c->raster_occ = (v == 4 || v == 6 || v == 8) ? v : 0; }
-    { const char *e = getenv("FRR_GEOM"); c->geom_force_scan = e && strcmp(e, "scan") == 0; c->geom_no_dense = e && strcmp(e, "nodense") == 0; }
     { const char *e = getenv("FRR_BIN_G"); c->bin_g = e ? atoi(e) : 0; }
     { const char *e = getenv("FRR_CLEAR"); c->clear_eager = e && strcmp(e, "eager") == 0; }
     { const char *e = getenv("FRR_ENT_SLOT"); c->ent_slot_override = e ? (uint32_t)atoi(e) : 0u; }
@@ -354,7 +356,7 @@ void frr_destroy(frr_ctx *c)
     prof_collect(c);
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
-    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->group_sums, c->block_sums_g, c->gidx, c->fast_list, c->fast_count, c->clip_list, c->recs, c->vary, c->pbox,
+    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->tinfo, c->fanbase, c->fan_okey, c->recs, c->vary, c->pbox,
                     c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bins2, c->bin_matrix};
     for (void *p : ptrs) if (p) (void)hipFree(p);
 #ifdef FRR_DEBUG_COUNTERS
@@ -456,7 +458,7 @@ static int mesh_register(frr_ctx *c, const float *dev, bool owned, uint64_t ntri
 int frr_mesh_upload(frr_ctx *c, const float *vs_inputs, uint64_t ntris, int vs_id, int *mesh_out)
 {
     if (!c || !mesh_out || frr_vs_input_floats(vs_id) < 0 || (ntris && !vs_inputs)) return fail(c, FRR_ERR_INVALID, "bad mesh");
-    if (ntris > 0x0FFFFFFFull) return fail(c, FRR_ERR_UNSUPPORTED, "more than 2^28 triangles per mesh");
+    if (ntris >= (1ull << 27)) return fail(c, FRR_ERR_UNSUPPORTED, "more than 2^27 triangles per mesh (order keys: 32 per input triangle)");
     HIP_TRY(c, hipSetDevice(c->device));
     size_t bytes = (size_t)ntris * 3 * frr_vs_input_floats(vs_id) * sizeof(float);
     void *d = nullptr;
@@ -471,7 +473,7 @@ int frr_mesh_upload(frr_ctx *c, const float *vs_inputs, uint64_t ntris, int vs_i
 int frr_mesh_bind_device(frr_ctx *c, const void *dev, uint64_t ntris, int vs_id, int *mesh_out)
 {
     if (!c || !mesh_out || frr_vs_input_floats(vs_id) < 0 || (ntris && !dev)) return fail(c, FRR_ERR_INVALID, "bad mesh");
-    if (ntris > 0x0FFFFFFFull) return fail(c, FRR_ERR_UNSUPPORTED, "more than 2^28 triangles per mesh");
+    if (ntris >= (1ull << 27)) return fail(c, FRR_ERR_UNSUPPORTED, "more than 2^27 triangles per mesh (order keys: 32 per input triangle)");
     if (((uintptr_t)dev & 15u) != 0) return fail(c, FRR_ERR_INVALID, "mesh pointer must be 16-byte aligned");
     return mesh_register(c, (const float *)dev, false, ntris, vs_id, mesh_out);
 }
@@ -530,6 +532,7 @@ static int clear_now(frr_ctx *c, uint32_t packed, float depth, bool counters)
 static int settle(frr_ctx *c)
 {
     HIP_TRY(c, hipSetDevice(c->device));
+    { int rcs = scan_now(c); if (rcs != FRR_OK) return rcs; }   // n_emit of the latest draw (statistics, setup read-back)
     if (c->clear_pending) {
         int rc = clear_now(c, c->clear_rgba, c->clear_depth, c->counters_pending);
         if (rc != FRR_OK) return rc;
@@ -549,6 +552,8 @@ int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
     HIP_TRY(c, hipSetDevice(c->device));
     uint32_t packed;
     memcpy(&packed, rgba, 4);
+    c->geom_ntris = 0;          // the setup list of a preceding frr_geometry is gone (frr_raster then draws nothing)
+    c->scan_pending = false;
     if (c->clear_eager) return clear_now(c, packed, depth, true);
     c->clear_rgba = packed; c->clear_depth = depth;
     c->clear_pending = c->counters_pending = true;
@@ -563,59 +568,48 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     const Mesh &m = c->meshes[mesh];
     const int K = frr_vs_num_varyings(m.vs);
     const uint64_t nt = m.ntris;
-    // worst case is 19 triangles out per triangle in (renderer.rs:150-171, 245-264)
-    uint64_t cap = nt <= (4u << 20) ? nt * FRR_MAX_OUT_TRIS : nt * 2 + 65536;
-    if (cap < c->setup_hint) cap = c->setup_hint;
-    if (cap < 1024) cap = 1024;
-    if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
-    const uint32_t nblocks = (uint32_t)((nt + GEOM_BLOCK - 1) / GEOM_BLOCK);
     int rc;
+    if ((rc = scan_now(c)) != FRR_OK) return rc;   // the previous draw's n_emit feeds this draw's tri_base
+    // fan region: clipped inputs are the ones that straddle a frustum plane, usually few; room for as many fan triangles
+    // as there are inputs (+ 4096) to start with, grown on demand (FRR_ERR_CAPACITY: the frame is re-issued) up to the
+    // worst case of 19 per input
+    // (meshes up to 55,000 triangles get their worst case outright: 2^20 slots are cheap)
+    uint64_t fan_cap = std::max<uint64_t>(std::max<uint64_t>(nt + 4096, std::min<uint64_t>(nt * FRR_MAX_OUT_TRIS, 1u << 20)), c->fan_hint);
+    fan_cap = std::min<uint64_t>(fan_cap, nt * FRR_MAX_OUT_TRIS);
+    if (nt + fan_cap > 0xFFFFFFF0ull) fan_cap = 0xFFFFFFF0ull - nt;
+    const size_t slots = (size_t)(nt + fan_cap);
+    const uint32_t nblocks = (uint32_t)((nt + GEOM_BLOCK - 1) / GEOM_BLOCK);
     if ((rc = ensure(c, c->block_sums, c->block_sums_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
-    if ((rc = ensure(c, c->clip_list, c->clip_list_cap, (size_t)std::max<uint64_t>(nt, 1))) != FRR_OK) return rc;
-    if ((rc = ensure(c, c->recs, c->setup_cap, (size_t)cap)) != FRR_OK) return rc;
+    if ((rc = ensure(c, c->tinfo, c->tinfo_cap, (size_t)std::max<uint64_t>(nt, 1))) != FRR_OK) return rc;
+    if ((rc = ensure(c, c->fanbase, c->fanbase_cap, (size_t)std::max<uint64_t>(nt, 1))) != FRR_OK) return rc;
+    if ((rc = ensure(c, c->fan_okey, c->fan_okey_cap, (size_t)std::max<uint64_t>(fan_cap, 1))) != FRR_OK) return rc;
+    if ((rc = ensure(c, c->recs, c->setup_cap, std::max<size_t>(slots, 1024))) != FRR_OK) return rc;
     if ((rc = ensure(c, c->pbox, c->pbox_cap, c->setup_cap)) != FRR_OK) return rc;
     if (K > 0 && (rc = ensure(c, c->vary, c->vary_cap, (size_t)c->setup_cap * 3 * 8 /* K <= 8 in the shader table */)) != FRR_OK) return rc;
     GeomArgs g;
     g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
-    g.cap = (uint32_t)std::min<size_t>(c->setup_cap, K > 0 ? c->vary_cap / (3 * (size_t)K) : c->setup_cap);
-    g.selfsum = 0;
+    g.fan_cap = (uint32_t)fan_cap;
     g.reset_frame = c->counters_pending ? 1 : 0; // (committed with the launch, below)
-    constexpr size_t kGroupSlot = (size_t)128 * GROUP_PAD; // 4 slots: {owned, all triangles} x {this draw, previous draw}
-    if (!c->group_sums) {
-        if ((rc = ensure(c, c->group_sums, c->group_sums_cap, 4 * kGroupSlot)) != FRR_OK) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->group_sums, 0, 4 * kGroupSlot * sizeof(uint32_t), c->stream));
-    }
-    // the per-draw slot (group sums, clipped-triangle counter) alternates; it is committed only when the draw's
-    // kernels are launched (a failed allocation below must not leave a slot toggled that nobody zeroed)
-    const int slot = c->geom_slot ^ 1;
-    g.group_sums = c->group_sums + (size_t)slot * kGroupSlot;
-    g.group_zero = c->group_sums + (size_t)(slot ^ 1) * kGroupSlot;
-    g.group_sums_g = c->group_sums + (size_t)(2 + slot) * kGroupSlot;
-    g.group_zero_g = c->group_sums + (size_t)(2 + (slot ^ 1)) * kGroupSlot;
-    // dense-owned draw: partitioned ctx + frr_draw (the window is known) + a mesh the emit blocks can offset themselves
-    g.dense = (filter && c->world > 1 && nblocks <= 8192 && !c->geom_force_scan && !c->geom_no_dense) ? 1 : 0;
-    g.block_sums_g = nullptr; g.gidx = nullptr; g.fast_list = nullptr; g.fast_count = nullptr;
-    if (g.dense) {
-        if ((rc = ensure(c, c->block_sums_g, c->block_sums_g_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
-        if ((rc = ensure(c, c->gidx, c->gidx_cap, c->setup_cap)) != FRR_OK) return rc;
-        if ((rc = ensure(c, c->fast_list, c->fast_list_cap, (size_t)nblocks * GEOM_BLOCK)) != FRR_OK) return rc;
-        if ((rc = ensure(c, c->fast_count, c->fast_count_cap, (size_t)nblocks)) != FRR_OK) return rc;
-        g.block_sums_g = c->block_sums_g; g.gidx = c->gidx; g.fast_list = c->fast_list; g.fast_count = c->fast_count;
-    }
     g.part_rank = c->rank; g.part_world = filter ? c->world : 1; g.part_y0 = fy0; g.part_y1 = fy1;
     g.part_rpr = 0;
     if (filter && c->part_blocked) {
         const int tiles_y = (int)(((int64_t)fy1 - fy0 + TILE - 1) / TILE);
         g.part_rpr = std::max(1, (tiles_y + c->world - 1) / c->world);
     }
+    // the per-draw slot (fan cursor) alternates; everything is committed only now that nothing can fail any more
+    // (a failed allocation above must not leave a slot toggled that nobody zeroed)
+    const int slot = c->geom_slot ^ 1;
+    g.fslot = slot;
+    g.block_sums = c->block_sums; g.tinfo = c->tinfo; g.fanbase = c->fanbase; g.fan_okey = c->fan_okey;
+    g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;
     // what the setup list about to be built was filtered by (frr_raster / frr_readback_setup check it)
     c->geom_filter = frr_ctx::GeomFilter{filter, fy0, fy1, c->rank, c->world, c->part_blocked};
     c->geom_slot = slot;
+    c->geom_fan_cap = (uint32_t)fan_cap;
+    c->geom_nblocks = nblocks;
     c->counters_pending = false;
-    g.block_sums = c->block_sums; g.clip_list = c->clip_list; g.cslot = slot;
-    g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;
     if (nt == 0) {
-        hipLaunchKernelGGL(k_geom_empty, dim3(1), dim3(128), 0, c->stream, g);
+        hipLaunchKernelGGL(k_geom_empty, dim3(1), dim3(64), 0, c->stream, g);
     } else {
         switch (m.vs) {
         case FRR_VS_CLIP: launch_geometry<FRR_VS_CLIP>(c, g, nblocks); break;
@@ -623,13 +617,15 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
         case FRR_VS_PHONG: launch_geometry<FRR_VS_PHONG>(c, g, nblocks); break;
         case FRR_VS_GOURAUD: launch_geometry<FRR_VS_GOURAUD>(c, g, nblocks); break;
         }
+        c->scan_pending = true;
     }
     HIP_TRY(c, hipGetLastError());
     c->geom_vs = m.vs; c->geom_ntris = nt;
     if (ntris_setup) {
+        if ((rc = scan_now(c)) != FRR_OK) return rc;
         Counters h;
         if ((rc = check_frame_counters(c, &h)) != FRR_OK) return rc;
-        *ntris_setup = h.n_setup;
+        *ntris_setup = h.n_emit;
     }
     return FRR_OK;
 }
@@ -727,13 +723,18 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xBFFFFFFFu);
         if ((rc = ensure(c, c->bins2, c->bin2_cap, (size_t)ntiles * S + a.bin_cap)) != FRR_OK) return rc;
         a.bins2 = c->bins2;
-        { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix, a.slot, stage_cap); }
+        // (+ one workgroup that scans the geometry kernel's block sums, unless an earlier launch has)
+        const int do_scan = c->scan_pending ? 1 : 0;
+        { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G + do_scan), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix, a.slot, stage_cap,
+                                                          c->geom_slot, c->geom_fan_cap, c->block_sums, c->geom_nblocks, do_scan); }
+        c->scan_pending = false;
     } else {
         // fallback for frames with more tiles than fit LDS counters: global atomics
-        const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((std::min<uint64_t>(c->geom_ntris * FRR_MAX_OUT_TRIS, c->setup_cap) + 255) / 256, 2048);
-        { ProfScope p(c, KID_BIN_COUNT); hipLaunchKernelGGL(k_bin<false>, dim3(bin_grid), dim3(256), 0, c->stream, a); }
+        if ((rc = scan_now(c)) != FRR_OK) return rc;
+        const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((c->geom_ntris + c->geom_fan_cap + 255) / 256, 2048);
+        { ProfScope p(c, KID_BIN_COUNT); hipLaunchKernelGGL(k_bin<false>, dim3(bin_grid), dim3(256), 0, c->stream, a, c->geom_slot, c->geom_fan_cap); }
         { ProfScope p(c, KID_TILE_SCAN); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, a, ntiles); }
-        { ProfScope p(c, KID_BIN_FILL); hipLaunchKernelGGL(k_bin<true>, dim3(bin_grid), dim3(256), 0, c->stream, a); }
+        { ProfScope p(c, KID_BIN_FILL); hipLaunchKernelGGL(k_bin<true>, dim3(bin_grid), dim3(256), 0, c->stream, a, c->geom_slot, c->geom_fan_cap); }
     }
     if (grid) {
         switch (ps_id) {
@@ -792,25 +793,37 @@ int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uin
     Counters h;
     int rc = check_frame_counters(c, &h);
     if (rc != FRR_OK) return rc;
-    *ntris = h.n_setup;
+    *ntris = h.n_emit;
     if (!out) return FRR_OK;
-    const uint64_t n = std::min<uint64_t>(h.n_setup, cap_tris);
+    // the records live at slots (frr_device.h): input t's own slot, or its fan's slots behind the inputs; walking the
+    // inputs in order and each fan in order is the reference's emission order
+    const uint64_t nt = c->geom_ntris;
+    const uint64_t slots = nt + std::min<uint64_t>(h.fan_cursor[c->geom_slot], c->geom_fan_cap);
     const int K = frr_vs_num_varyings(c->geom_vs);
-    std::vector<RasterRec> recs(n);
-    std::vector<float> vary((size_t)n * 3 * K);
-    if (n) HIP_TRY(c, hipMemcpy(recs.data(), c->recs, n * sizeof(RasterRec), hipMemcpyDeviceToHost));
-    if (n && K) HIP_TRY(c, hipMemcpy(vary.data(), c->vary, vary.size() * sizeof(float), hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < n; ++i) {
-        const RasterRec &r = recs[i];
-        const bool sw = r.flags & 1u;
-        for (int v = 0; v < 3; ++v) {
-            const int s = sw ? (v == 1 ? 2 : (v == 2 ? 1 : 0)) : v; // undo the orientation swap
-            frr_setup_vertex &o = out[i * 3 + v];
-            memset(&o, 0, sizeof o);
-            o.spf[0] = r.s[2 * s]; o.spf[1] = r.s[2 * s + 1];
-            o.spi[0] = r.p[2 * s]; o.spi[1] = r.p[2 * s + 1];
-            o.rhw = r.rhw[s];
-            for (int k = 0; k < K; ++k) o.ctx[k] = vary[(size_t)i * 3 * K + (size_t)s * K + k];
+    std::vector<uint32_t> tinfo(nt), fanbase(nt);
+    std::vector<RasterRec> recs(slots);
+    std::vector<float> vary((size_t)slots * 3 * K);
+    if (nt) HIP_TRY(c, hipMemcpy(tinfo.data(), c->tinfo, nt * 4, hipMemcpyDeviceToHost));
+    if (nt) HIP_TRY(c, hipMemcpy(fanbase.data(), c->fanbase, nt * 4, hipMemcpyDeviceToHost));
+    if (slots) HIP_TRY(c, hipMemcpy(recs.data(), c->recs, slots * sizeof(RasterRec), hipMemcpyDeviceToHost));
+    if (slots && K) HIP_TRY(c, hipMemcpy(vary.data(), c->vary, vary.size() * sizeof(float), hipMemcpyDeviceToHost));
+    uint64_t i = 0;
+    for (uint64_t t = 0; t < nt && i < cap_tris; ++t) {
+        const uint32_t n = tinfo[t] & ((1u << FAN_BITS) - 1u);
+        for (uint32_t q = 0; q < n && i < cap_tris; ++q, ++i) {
+            const uint64_t slot = n == 1u ? t : nt + fanbase[t] + q;     // (a clipped input emits at least two triangles)
+            if (slot >= slots) return fail(c, FRR_ERR_HIP, "setup tables are inconsistent");
+            const RasterRec &r = recs[slot];
+            const bool sw = r.flags & 1u;
+            for (int v = 0; v < 3; ++v) {
+                const int s = sw ? (v == 1 ? 2 : (v == 2 ? 1 : 0)) : v; // undo the orientation swap
+                frr_setup_vertex &o = out[i * 3 + v];
+                memset(&o, 0, sizeof o);
+                o.spf[0] = r.s[2 * s]; o.spf[1] = r.s[2 * s + 1];
+                o.spi[0] = r.p[2 * s]; o.spi[1] = r.p[2 * s + 1];
+                o.rhw = r.rhw[s];
+                for (int k = 0; k < K; ++k) o.ctx[k] = vary[(size_t)slot * 3 * K + (size_t)s * K + k];
+            }
         }
     }
     return FRR_OK;
@@ -824,7 +837,7 @@ int frr_get_stats(frr_ctx *c, frr_stats *out)
     HIP_TRY(c, hipMemcpyAsync(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     out->tris_in = h.tris_in;
-    out->tris_setup = (uint64_t)h.tri_base + h.n_emit;
+    out->tris_setup = (uint64_t)h.tri_base + h.n_emit;   // (settle() has scanned the latest draw's block sums)
     out->bin_entries = h.bin_entries_frame + h.seg_total[0] + h.seg_total[1];
     out->frag_covered = h.frag_covered;
     out->frag_nan = h.frag_nan;

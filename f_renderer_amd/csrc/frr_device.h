@@ -31,29 +31,44 @@ constexpr int DBG_COPIES = 1;
 #endif
 
 struct Counters {
-    uint32_t n_setup;       // setup triangles of the current draw
-    uint32_t n_emit;        // triangles the current draw emits in the reference's numbering (== n_setup unless the draw is dense-owned)
+    uint32_t n_emit;        // triangles the current draw emits (the reference's count; known once the block sums are scanned)
     uint32_t tri_base;      // emission index of this draw's first triangle within the frame
-    uint32_t overflow;      // bit0 setup capacity, bit1 bin capacity
-    uint64_t bin_total;     // (triangle,tile) pairs of the current draw
+    uint32_t overflow;      // bit0 fan capacity, bit1 bin capacity, bit2 order keys exhausted
+    uint32_t ntris_draw;    // input triangles of the current draw (= its first fan slot)
+    uint64_t bin_total;     // (triangle,tile) pairs of the current draw (CSR binning)
     uint64_t frag_covered;  // since last clear
     uint64_t frag_nan;
     uint64_t tris_in;
     uint64_t bin_entries_frame;
     uint32_t draws;
-    uint32_t need_setup;    // setup triangles the current draw needs (valid even on overflow)
-    uint32_t reserved1;
-    uint32_t pad0;
+    uint32_t need_fans;     // fan slots the current draw needs (valid even on overflow)
+    uint32_t pad0, pad1;
     unsigned long long seg_total[2]; // segmented binning: entries reserved by the current / previous draw (slots alternate per draw)
-    uint32_t clip_n[2];              // clipped triangles listed by the current / previous draw's k_geom_count (slots alternate)
-    uint32_t ent_cursor[2];
-    const uint32_t *gidx;            // dense-owned draw: emission index of each setup slot, else null (set by k_geom_count; read by the
-                                     // resolve like tri_base -- a kernel argument would cost the tile kernel its sixth wave per SIMD)          // tile kernel: space handed out in the overflow arena of bins2 (same slots)
+    uint32_t fan_cursor[2];          // fan slots handed out by the current / previous draw's geometry kernel (slots alternate)
+    uint32_t ent_cursor[2];          // tile kernel: space handed out in the overflow arena of bins2 (same slots)
+    // per-draw tables the tile kernel's resolve reads (set by the geometry kernel; kernel arguments would cost it registers)
+    const uint32_t *tinfo;           // [ntris] fan size (bits 0-4) | emission offset within its 256-triangle block (bits 5..)
+    const uint32_t *fanbase;         // [ntris] clipped inputs: first fan slot, relative to ntris_draw
+    const uint32_t *fan_okey;        // [fan slots] order key (within the draw) of each fan triangle
+    const uint32_t *block_prefix;    // [blocks] triangles emitted by the blocks before (exclusive scan of the block sums)
     // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py): funnel counters and per-phase wave cycles of the tile
     // kernel, in DBG_COPIES copies (workgroup b adds to copy b % DBG_COPIES: thousands of device atomics on one cache
     // line would serialise at ~17 ns each and distort what they measure); the host adds the copies up
     unsigned long long dbg[DBG_COPIES][24];
 };
+
+// ---- slots and order keys --------------------------------------------------------------------------------------
+// A draw's setup triangles live at SLOTS: input triangle t that emits exactly one triangle (the common, unclipped
+// case) uses slot t; the fan of a clipped input (2..19 triangles, renderer.rs:245-264) takes consecutive slots of
+// the fan region behind the inputs (slot = ntris + fanbase[t] + q), handed out by one atomic per geometry block.
+// Nothing has to be counted before it can be placed, so geometry is ONE pass.  Slots are not in emission order,
+// but the z tie-break (renderer.rs:363: the later triangle wins) only needs a key that is: the ORDER KEY of a
+// triangle is  32 * t  for an unclipped input and  32 * t + 1 + q  for fan triangle q -- monotone in the reference's
+// emission order within the draw (2^27 input triangles per mesh).  Keys of different draws never meet: a draw starts
+// from the depth buffer with id 0 = "what was there", which any fragment of equal depth beats.  The tile kernel keeps
+// order key + 1  in the low half of its 64-bit pixel keys; the resolve maps a winner back to its slot and to the
+// reference's emission index  tri_base + block_prefix[t / 256] + (tinfo[t] >> 5) + q.
+constexpr int FAN_BITS = 5;
 
 struct DevUniforms {
     float mvp[16];     // (proj*view)*model, phong.rs:119 hoisted (pure, so exact)
@@ -67,36 +82,23 @@ struct DevUniforms {
     uint32_t tex_w, tex_h;
 };
 
-constexpr int GROUP_PAD = 32; // one 128-byte line per group counter: device atomics on one line serialise (~17 ns each)
-
 struct GeomArgs {
     const float *in;        // [ntris][3][NF]
     uint32_t ntris;
     uint32_t width, height; // viewport of renderer.rs:107-108
-    uint32_t cap;           // setup capacity (triangles)
-    int32_t selfsum;        // emit blocks sum the block counts themselves (no k_scan_blocks launch)
+    uint32_t fan_cap;       // capacity of the fan region (triangles)
     int32_t reset_frame;    // first draw after frr_clear: the bookkeeping thread zeroes the frame counters first
-    uint32_t *group_sums;   // [128 groups][GROUP_PAD]: setup triangles per group of 64 count blocks, this draw's slot ...
-    uint32_t *group_zero;   // ... and the previous draw's slot, zeroed by this draw's count kernel
     int32_t part_rank, part_world; // tile-row ownership filter (world == 1: none); only set by frr_draw,
     int32_t part_y0, part_y1;      // which knows the raster window's height range
     int32_t part_rpr;              // > 0: blocked partition (RasterArgs::rpr)
-    // Dense-owned draws (partitioned ctx, frr_draw, <= 8192 count blocks): triangles that touch none of the
-    // rank's tile rows get NO setup slot at all -- offsets come from the sums of the owned triangles
-    // (block_sums / group_sums), the reference's emission index of every slot is kept in gidx[] and derived
-    // from the sums over all triangles (block_sums_g / group_sums_g).  Binning and the tile kernel then see
-    // 1/N of the triangles; ids and z tie-breaks are unchanged (the dense order is the emission order).
-    int32_t dense;
-    uint32_t *block_sums_g, *group_sums_g, *group_zero_g;
-    uint32_t *gidx;                // [cap] emission index (within the draw) of each setup slot
-    uint2 *fast_list;              // [nblocks][256] per count block: its owned, unclipped triangles (thread | offset in block << 8, emission offset in block)
-    uint32_t *fast_count;          // [nblocks]
-    uint32_t *block_sums;   // [nblocks] setup triangles per count block; exclusive-scanned in place by k_scan_blocks (MODE 0)
-    uint4 *clip_list;       // [<= ntris] clipped triangles of this draw: (input index, offset within its block | fan size << 16, emission offset within its block, 0)
-    int32_t cslot;          // Counters::clip_n slot of this draw
-    RasterRec *recs;
-    float *vary;
-    uint4 *pbox;            // per setup triangle, the binning input: {minx|miny<<16, maxx|maxy<<16 (i16 pixel bbox of spi), zkey of an upper bound of |rhw|, 0}
+    int32_t fslot;          // Counters::fan_cursor slot of this draw
+    uint32_t *block_sums;   // [nblocks] triangles emitted per 256-triangle block; scanned in place into Counters::block_prefix
+    uint32_t *tinfo;        // [ntris]   see Counters
+    uint32_t *fanbase;      // [ntris]
+    uint32_t *fan_okey;     // [fan_cap]
+    RasterRec *recs;        // [ntris + fan_cap]
+    float *vary;            // [ntris + fan_cap][3][K]
+    uint4 *pbox;            // per slot, the binning input: {minx|miny<<16, maxx|maxy<<16 (i16 pixel bbox of spi), zkey of an upper bound of |rhw|, 0}; all zero = nothing here
     Counters *cnt;
 };
 
@@ -144,8 +146,10 @@ __device__ __forceinline__ bool owns_tile_row(int ty, int rank, int world, int r
 // what frr_clear does to the counters (by k_clear, or deferred to the next draw's bookkeeping thread)
 __device__ __forceinline__ void reset_frame_counters(Counters *cnt)
 {
-    cnt->n_setup = 0; cnt->n_emit = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
+    cnt->n_emit = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
     cnt->seg_total[0] = cnt->seg_total[1] = 0ull; cnt->ent_cursor[0] = cnt->ent_cursor[1] = 0u;
+    // (NOT the fan cursors: the bookkeeping thread that calls this runs beside geometry blocks that are already
+    // allocating from the current draw's cursor; every geometry kernel zeroes the OTHER slot for the next draw)
     cnt->frag_covered = 0; cnt->frag_nan = 0; cnt->tris_in = 0; cnt->bin_entries_frame = 0; cnt->draws = 0;
     for (int j = 0; j < DBG_COPIES; ++j) for (int k = 0; k < 24; ++k) cnt->dbg[j][k] = 0;
 }

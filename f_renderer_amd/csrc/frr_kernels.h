@@ -70,152 +70,24 @@ __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t *s_w
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1a geometry count: VS x3 + classification (renderer.rs:113-174) -> triangles per input,
-// reduced per 256-triangle block.  HBM: reads the input triangles once.
-// ---------------------------------------------------------------------------------------------
-template <int VS>
-__global__ __launch_bounds__(GEOM_BLOCK) void k_geom_count(GeomArgs g, DevUniforms u)
-{
-    __shared__ uint32_t s_w[4], s_wg[4];
-    __shared__ uint32_t s_nclip, s_cbase, s_nfast;
-    constexpr int NF = VSInfo<VS>::NF;
-    const uint32_t t = blockIdx.x * GEOM_BLOCK + threadIdx.x;
-    if (threadIdx.x == 0) s_nfast = 0; // (ordered like s_nclip)
-    uint32_t n = 0;    // triangles this input emits (the reference's count)
-    uint32_t nl = 0;   // ... of which this rank keeps a setup slot (dense-owned draws: none for unowned triangles)
-    bool clipped = false;
-    if (threadIdx.x == 0) s_nclip = 0; // ordered before its use by the barrier inside block_excl_scan256
-    if (t < g.ntris) {
-        float pos[3][4];
-        const float *in = g.in + (size_t)t * (3 * NF);
-#pragma unroll
-        for (int v = 0; v < 3; ++v) run_vs<VS, false>(u, in + v * NF, pos[v], nullptr);
-        n = classify(pos, clipped);
-        nl = n;
-        if (g.dense && n != 0u && !clipped) {
-            const float fw = (float)g.width, fh = (float)g.height;
-            const ScreenVtx s0 = to_screen(pos[0], fw, fh), s1 = to_screen(pos[1], fw, fh), s2 = to_screen(pos[2], fw, fh);
-            if (!tri_rows_owned(g, s0.iy, s1.iy, s2.iy)) nl = 0u;
-        }
-    }
-    uint32_t total, total_g = 0, goff_local = 0;
-    const uint32_t off_local = block_excl_scan256(nl, s_w, total);
-    if (g.dense) goff_local = block_excl_scan256(n, s_wg, total_g);
-    if (threadIdx.x == 0) { g.block_sums[blockIdx.x] = total; if (g.dense) g.block_sums_g[blockIdx.x] = total_g; }
-    // clipped triangles that emit anything go on the draw's global list: (input index, offset within the
-    // block | fan size << 16); one returning atomic per block that has any
-    const bool listed = clipped && n != 0u;
-    uint32_t crank = 0;
-    if (listed) crank = atomicAdd(&s_nclip, 1u);
-    // dense-owned draws: the block's owned, unclipped triangles are listed too (any order: each entry carries
-    // its offsets), so that k_geom_emit touches only those -- 1/N of the inputs on a rank of N
-    const bool fast = g.dense && nl != 0u && !clipped;
-    if (fast) g.fast_list[(size_t)blockIdx.x * GEOM_BLOCK + atomicAdd(&s_nfast, 1u)] = make_uint2(threadIdx.x | (off_local << 8), goff_local);
-    __syncthreads();
-    if (g.dense && threadIdx.x == 0) g.fast_count[blockIdx.x] = s_nfast;
-    const uint32_t nclip = s_nclip;
-    if (nclip) {
-        if (threadIdx.x == 0) s_cbase = atomicAdd(&g.cnt->clip_n[g.cslot], nclip);
-        __syncthreads();
-        if (listed) g.clip_list[s_cbase + crank] = make_uint4(t, off_local | (n << 16), goff_local, 0u);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        g.cnt->clip_n[g.cslot ^ 1] = 0u; // the previous draw's list, for the next draw
-        g.cnt->gidx = g.dense ? g.gidx : nullptr;
-    }
-    // The other slot of the two-level sums (both sets) belongs to the previous draw and is zeroed for the next one
-    // by EVERY draw, whichever path it takes itself (self-summing or k_scan_blocks, dense-owned or not): the slots
-    // alternate per draw, so a path that skipped this would hand stale sums to the draw after it.
-    if (blockIdx.x == 0 && threadIdx.x < 128) {
-        g.group_zero[threadIdx.x * GROUP_PAD] = 0u;
-        g.group_zero_g[threadIdx.x * GROUP_PAD] = 0u;
-    }
-    if (g.selfsum) {
-        // two-level sums for the emit blocks: one fire-and-forget atomic per block on its group's counter
-        // (64 blocks per counter, one cache line per counter)
-        if (threadIdx.x == 0 && total) atomicAdd(&g.group_sums[(blockIdx.x >> 6) * GROUP_PAD], total);
-        if (g.dense && threadIdx.x == 0 && total_g) atomicAdd(&g.group_sums_g[(blockIdx.x >> 6) * GROUP_PAD], total_g);
-    }
-    if (g.selfsum && blockIdx.x == 0 && threadIdx.x == 0) { // per-draw bookkeeping k_scan_blocks would do
-        if (g.reset_frame) reset_frame_counters(g.cnt);
-        g.cnt->tri_base += g.cnt->n_emit;                   // previous draw's triangles precede this draw's
-        g.cnt->tris_in += g.ntris;
-        g.cnt->draws += 1;
-    }
-}
-
-// An empty mesh launches no count kernel; this does what its block 0 would have done for the NEXT draw (zero the
-// other slot of the group sums and of the clipped-triangle counter) and then k_scan_blocks' bookkeeping.
-__global__ __launch_bounds__(128) void k_geom_empty(GeomArgs g)
-{
-    g.group_zero[threadIdx.x * GROUP_PAD] = 0u;
-    g.group_zero_g[threadIdx.x * GROUP_PAD] = 0u;
-    if (threadIdx.x == 0) {
-        Counters *cnt = g.cnt;
-        cnt->clip_n[g.cslot ^ 1] = 0u;
-        cnt->gidx = nullptr;
-        if (g.reset_frame) reset_frame_counters(cnt);
-        cnt->tri_base += cnt->n_emit;
-        cnt->need_setup = 0; cnt->n_setup = 0; cnt->n_emit = 0;
-        cnt->draws += 1;
-    }
-}
-
-// K1b: exclusive scan of the block sums (single workgroup), publishes n_setup, advances tri_base.
-__global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t *__restrict__ sums, uint32_t nblocks, uint32_t cap,
-                                                      uint32_t ntris, Counters *cnt, int reset_frame)
-{
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < nblocks; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < nblocks ? sums[i] : 0u;
-        uint32_t inc = wave_incl_scan(v);
-        if (lane == 63) s_w[w] = inc;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { uint32_t x = s_w[k]; if (k < w) wbase += x; tot += x; }
-        uint32_t carry = s_carry;
-        if (i < nblocks) sums[i] = carry + wbase + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        uint32_t total = s_carry;
-        if (reset_frame) reset_frame_counters(cnt);
-        cnt->tri_base += cnt->n_emit; // previous draw's triangles precede this draw's in the frame
-        cnt->need_setup = total;
-        if (total > cap) { cnt->overflow |= 1u; total = 0; }
-        cnt->n_setup = total;
-        cnt->n_emit = total;
-        cnt->tris_in += ntris;
-        cnt->draws += 1;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1c geometry emit, unclipped fast path: renderer.rs:113-148 (VS, reject, classify),
-// :180-218 (centroid + stable angle sort of 3), :220-235 (divide, viewport, snap), :237-243,
-// then the per-triangle prologue of rasterization (:300-320) so the record is ready to scan.
-// Clipped triangles were listed by k_geom_count (GeomArgs::clip_list); after its own triangles every
-// wave of the grid takes its share of that list (clip_triangle_wave: one wave per clipped triangle), so
-// a mesh whose clipped triangles are clustered (a screen-filling sheet) does not serialise on a few blocks.
+// K1 geometry in ONE pass (slots and order keys: frr_device.h).  Thread = input triangle:
+// renderer.rs:113-148 (VS, reject, classify), then for the common unclipped case :180-218 (centroid +
+// stable angle sort of 3), :220-235 (divide, viewport, snap), :237-243 and the per-triangle prologue of
+// rasterization (:300-320), so that the record at slot t is ready to scan.  Clipped inputs reserve their
+// fan slots with ONE atomic per block and are then expanded by the block's four waves, one wave per
+// triangle (clip_triangle_wave).  Per block the kernel leaves the number of triangles it emits
+// (block_sums, scanned later: geom_scan) and per input its fan size and emission offset (tinfo).
+// HBM: reads the inputs once, writes 64 + 16 (+ 12K) bytes per emitted triangle.
 // ---------------------------------------------------------------------------------------------
 // Clipped triangles: the reference's quirky clipper (renderer.rs:150-171: one intersection per
 // (edge, plane) with differing in/out flags, outside vertices kept), centroid + stable angle sort of
 // up to 21 vertices (:180-218), fan emission (:245-266) -- done by ONE WAVE per triangle:
 // lanes 0..17 = the 3 pairs x 6 planes in the reference's loop order, lanes 18..20 = the originals,
 // so "list order" is simply lane order among the kept lanes.
-// ---------------------------------------------------------------------------------------------
 constexpr int CLIP_MAXV = 21;
 
 template <int VS>
-__device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevUniforms &u, uint32_t t, uint32_t off, uint32_t goff, int lane,
+__device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevUniforms &u, uint32_t t, uint32_t fbase, int lane,
                                                    float (*s_xy)[2], int32_t *s_key, float (*s_v)[7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)])
 {
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K, KS = K > 0 ? K : 1;
@@ -287,8 +159,9 @@ __device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevU
         flags |= is_top_left(p0x, p0y, p1x, p1y) ? 0u : 2u;                                // :318-320
         flags |= is_top_left(p1x, p1y, p2x, p2y) ? 0u : 4u;
         flags |= is_top_left(p2x, p2y, p0x, p0y) ? 0u : 8u;
-        const uint32_t idx = off + (uint32_t)q;
-        if (g.dense) g.gidx[idx] = goff + (uint32_t)q;
+        const uint32_t fslot = fbase + (uint32_t)q;             // fan triangle q of input t: emission order is q order
+        const uint32_t idx = g.ntris + fslot;
+        g.fan_okey[fslot] = (t << FAN_BITS) + 1u + (uint32_t)q;
         { const uint2 pb = pack_pbox(p0x, p0y, p1x, p1y, p2x, p2y); g.pbox[idx] = make_uint4(pb.x, pb.y, cull_zub(v0[0], v1[0], v2[0]), 0u); }
         uint4 *dst = reinterpret_cast<uint4 *>(g.recs + idx);
         dst[0] = make_uint4((uint32_t)p0x, (uint32_t)p0y, (uint32_t)p1x, (uint32_t)p1y);
@@ -304,100 +177,73 @@ __device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevU
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // staging is reused by the wave's next triangle
 }
 
-// MODE 0: block_sums were exclusive-scanned by k_scan_blocks;
-// MODE 2: every block derives its prefix from the two-level sums itself (<= 8192 blocks: cheaper than a scan launch).
-template <int VS, int MODE>
-__global__ __launch_bounds__(GEOM_BLOCK, 6) void k_geom_emit(GeomArgs g, DevUniforms u)
+// per-draw bookkeeping, by ONE thread of the draw's geometry kernel.  It runs beside the kernel's other blocks, so it
+// touches nothing they touch: the fan cursor of THIS draw was zeroed by the draw before (every geometry path zeroes
+// the other slot -- the slots alternate per draw), and flags are raised only by later kernels (geom_scan, binning).
+__device__ __forceinline__ void geom_bookkeeping(const GeomArgs &g)
 {
-    __shared__ uint32_t s_w[4], s_wg[4];
+    Counters *cnt = g.cnt;
+    if (g.reset_frame) reset_frame_counters(cnt);
+    cnt->tri_base += cnt->n_emit;          // the previous draw's triangles precede this draw's (its block sums are scanned by now)
+    cnt->n_emit = 0u;
+    cnt->fan_cursor[g.fslot ^ 1] = 0u;
+    cnt->ntris_draw = g.ntris;
+    cnt->tinfo = g.tinfo; cnt->fanbase = g.fanbase; cnt->fan_okey = g.fan_okey; cnt->block_prefix = g.block_sums;
+    cnt->tris_in += g.ntris;
+    cnt->draws += 1;
+}
+
+template <int VS>
+__global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUniforms u)
+{
+    __shared__ uint32_t s_w[4], s_wf[4];
     __shared__ uint4 s_stage[GEOM_BLOCK / 64][64 * 5];    // per wave: 64 records at an 80-byte stride (see the record stores)
     __shared__ float s_cxy[GEOM_BLOCK / 64][CLIP_MAXV][2]; // per wave: clip x,y in list order
     __shared__ int32_t s_ckey[GEOM_BLOCK / 64][CLIP_MAXV];
     __shared__ float s_cv[GEOM_BLOCK / 64][CLIP_MAXV][7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)];
+    __shared__ uint32_t s_cl[GEOM_BLOCK];                 // the block's clipped inputs: thread | fan offset within the block << 8
+    __shared__ uint32_t s_ncl, s_fbase;
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K;
     const uint32_t bid = blockIdx.x;
+    const uint32_t t = bid * GEOM_BLOCK + threadIdx.x;
+    if (bid == 0 && threadIdx.x == 0) geom_bookkeeping(g);
+    if (threadIdx.x == 0) s_ncl = 0; // ordered before its use by the barriers inside block_excl_scan256
     float pos[3][4];
     float ctx[3][K > 0 ? K : 1];
-    uint32_t n = 0;   // the reference's count for this input
-    uint32_t nl = 0;  // setup slots this rank keeps for it
+    uint32_t n = 0;   // triangles this input emits (the reference's count)
     bool clipped = false;
+    if (t < g.ntris) {
+        const float *in = g.in + (size_t)t * (3 * NF);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
+        n = classify(pos, clipped);
+    }
+    uint32_t total, ftotal;
+    const uint32_t eoff = block_excl_scan256(n, s_w, total);                    // emission offset within the block
+    const uint32_t foff = block_excl_scan256(clipped ? n : 0u, s_wf, ftotal);   // fan slots of the clipped inputs before this one
+    if (threadIdx.x == 0) {
+        g.block_sums[bid] = total;
+        s_fbase = ftotal ? atomicAdd(&g.cnt->fan_cursor[g.fslot], ftotal) : 0u;  // ONE returning atomic per block that clips anything
+    }
+    if (t < g.ntris) g.tinfo[t] = n | (eoff << FAN_BITS);
+    __syncthreads();
+    const uint32_t fbase = s_fbase;
+    const bool fans_ok = fbase + ftotal <= g.fan_cap;  // else the frame is flagged invalid by geom_scan (cursor > capacity) and re-issued
+    if (clipped) {
+        g.fanbase[t] = fbase + foff;
+        if (fans_ok) s_cl[atomicAdd(&s_ncl, 1u)] = threadIdx.x | (foff << 8);
+    }
+    // Multi-GPU: a rank that owns none of the tile rows an (unclipped) triangle's bbox touches never reads its record
+    // (geometry is replicated, so this is what keeps the replicated part small); clipped fans are kept on every rank
     ScreenVtx s0 = {}, s1 = {}, s2 = {};
-    bool owned = true;
-    uint32_t total, total_g = 0, goff = 0, off;
-    if (MODE == 2 && g.dense) {
-        // dense-owned draw: thread j takes the j-th entry of the block's list of owned, unclipped triangles
-        // (k_geom_count); everything else of the block needs no work here
-        const uint32_t cntf = g.fast_count[bid];
-        total = g.block_sums[bid];
-        total_g = g.block_sums_g[bid];
-        off = 0;
-        if (threadIdx.x < cntf) {
-            const uint2 e = g.fast_list[(size_t)bid * GEOM_BLOCK + threadIdx.x];
-            const uint32_t t = bid * GEOM_BLOCK + (e.x & 255u);
-            const float *in = g.in + (size_t)t * (3 * NF);
-#pragma unroll
-            for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
-            const float fw = (float)g.width, fh = (float)g.height;
-            s0 = to_screen(pos[0], fw, fh); s1 = to_screen(pos[1], fw, fh); s2 = to_screen(pos[2], fw, fh);
-            n = nl = 1u;
-            off = e.x >> 8;
-            goff = e.y;
-        }
-    } else {
-        const uint32_t t = bid * GEOM_BLOCK + threadIdx.x;
-        if (t < g.ntris) {
-            const float *in = g.in + (size_t)t * (3 * NF);
-#pragma unroll
-            for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
-            n = classify(pos, clipped);
-            nl = n;
-            if (n != 0u && !clipped) {
-                const float fw = (float)g.width, fh = (float)g.height;
-                s0 = to_screen(pos[0], fw, fh); s1 = to_screen(pos[1], fw, fh); s2 = to_screen(pos[2], fw, fh);
-                // Multi-GPU: a rank that owns none of the tile rows this triangle's bbox touches never reads its
-                // record (geometry is replicated, so this is what keeps the replicated part small)
-                owned = tri_rows_owned(g, s0.iy, s1.iy, s2.iy);
-            }
-        }
-        off = block_excl_scan256(nl, s_w, total);
+    bool emit = false;
+    if (n == 1u && !clipped) {
+        const float fw = (float)g.width, fh = (float)g.height;
+        s0 = to_screen(pos[0], fw, fh); s1 = to_screen(pos[1], fw, fh); s2 = to_screen(pos[2], fw, fh);
+        emit = tri_rows_owned(g, s0.iy, s1.iy, s2.iy);
     }
-    if constexpr (MODE == 2) {
-        // exclusive prefix of this block = groups before its group (<= 127 counters, threads 0..126)
-        // + the blocks before it in its own group (<= 63 block sums, threads 128..190): one load per thread
-        // (two in a dense-owned draw: the same sums over ALL triangles give the emission indices)
-        uint32_t part = 0, part_g = 0;
-        const uint32_t grp = bid >> 6, inb = bid & 63u;
-        if (threadIdx.x < grp) {
-            part = g.group_sums[threadIdx.x * GROUP_PAD];
-            if (g.dense) part_g = g.group_sums_g[threadIdx.x * GROUP_PAD];
-        } else if (threadIdx.x >= 128u && threadIdx.x - 128u < inb) {
-            part = g.block_sums[(grp << 6) + threadIdx.x - 128u];
-            if (g.dense) part_g = g.block_sums_g[(grp << 6) + threadIdx.x - 128u];
-        }
-        const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(part), 63);
-        const uint32_t wsum_g = g.dense ? (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(part_g), 63) : 0u;
-        __syncthreads();                       // s_w / s_wg were read by block_excl_scan256 above
-        if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = wsum; s_wg[threadIdx.x >> 6] = wsum_g; }
-        __syncthreads();
-        const uint32_t excl = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        const uint32_t excl_g = s_wg[0] + s_wg[1] + s_wg[2] + s_wg[3];
-        off += excl;
-        goff += excl_g;
-        if (threadIdx.x == 0 && bid == gridDim.x - 1) { // the last block knows the grand totals
-            const uint32_t all = excl + total;
-            g.cnt->need_setup = all;
-            if (all > g.cap) atomicOr(&g.cnt->overflow, 1u);
-            g.cnt->n_setup = all > g.cap ? 0u : all;
-            g.cnt->n_emit = g.dense ? excl_g + total_g : (all > g.cap ? 0u : all);
-        }
-    } else {
-        off += g.block_sums[blockIdx.x];
-    }
-    // nothing to emit (None / dropped / not this rank's) or capacity overflow (the frame is flagged invalid)
-    const bool emit_ok = nl != 0 && (MODE != 0 ? off + nl <= g.cap : g.cnt->n_setup != 0u);
-    if (emit_ok && !clipped) { // (clipped triangles: the draw's list, below)
-    if (!owned) g.pbox[off] = make_uint4(0u, 0u, 0u, 0u); // not dense: the slot exists but stays empty for the binning
-    if (owned) {
+    if (t < g.ntris && !emit) g.pbox[t] = make_uint4(0u, 0u, 0u, 0u); // nothing at slot t (dropped / clipped / not this rank's)
+    if (emit) {
     // centroid (:180-187), n == 3
     float cx = 0.0f, cy = 0.0f;
 #pragma unroll
@@ -462,75 +308,95 @@ __global__ __launch_bounds__(GEOM_BLOCK, 6) void k_geom_emit(GeomArgs g, DevUnif
     flags |= is_top_left(px[0], py[0], px[1], py[1]) ? 0u : 2u;           // :318-320
     flags |= is_top_left(px[1], py[1], px[2], py[2]) ? 0u : 4u;
     flags |= is_top_left(px[2], py[2], px[0], py[0]) ? 0u : 8u;
-    { const uint2 pb = pack_pbox(px[0], py[0], px[1], py[1], px[2], py[2]); g.pbox[off] = make_uint4(pb.x, pb.y, cull_zub(rw[0], rw[1], rw[2]), 0u); }
+    { const uint2 pb = pack_pbox(px[0], py[0], px[1], py[1], px[2], py[2]); g.pbox[t] = make_uint4(pb.x, pb.y, cull_zub(rw[0], rw[1], rw[2]), 0u); }
     const uint4 q0 = make_uint4((uint32_t)px[0], (uint32_t)py[0], (uint32_t)px[1], (uint32_t)py[1]);
     const uint4 q1 = make_uint4((uint32_t)px[2], (uint32_t)py[2], f2u(sx[0]), f2u(sy[0]));
     const uint4 q2 = make_uint4(f2u(sx[1]), f2u(sy[1]), f2u(sx[2]), f2u(sy[2]));
     const uint4 q3 = make_uint4(f2u(rw[0]), f2u(rw[1]), f2u(rw[2]), flags);
     {
-        // The lanes that are here emit exactly one triangle each; unless a clipped triangle sits between them
-        // their records are consecutive in memory.  A lane-per-record store writes 16 B at a 64-B stride (64
-        // partial-line writes per instruction, write-through); staged through LDS (80-B record stride:
+        // The lanes that are here write the record of their own slot t; when they are a run of consecutive lanes (the
+        // usual case: every lane) the records are consecutive in memory.  A lane-per-record store writes 16 B at a 64-B
+        // stride (64 partial-line writes per instruction, write-through); staged through LDS (80-B record stride:
         // conflict-free b128 writes) the same bytes leave as fully coalesced stores.
         const unsigned long long am = __ballot(true);
         const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
         const int np = __popcll(am);
-        const uint32_t off0 = __builtin_amdgcn_readfirstlane(off);
-        if (__ballot(off == off0 + (uint32_t)rk) == am) {
+        const uint32_t t0 = __builtin_amdgcn_readfirstlane(t);
+        if (__ballot(t == t0 + (uint32_t)rk) == am) {
             uint4 *st = s_stage[threadIdx.x >> 6];
             st[rk * 5 + 0] = q0; st[rk * 5 + 1] = q1; st[rk * 5 + 2] = q2; st[rk * 5 + 3] = q3;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint4 *dst = reinterpret_cast<uint4 *>(g.recs + off0);
+            uint4 *dst = reinterpret_cast<uint4 *>(g.recs + t0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const int c = rk + j * np; dst[c] = st[(c >> 2) * 5 + (c & 3)]; }
         } else {
-            uint4 *dst = reinterpret_cast<uint4 *>(g.recs + off);
+            uint4 *dst = reinterpret_cast<uint4 *>(g.recs + t);
             dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
         }
     }
-    if (g.dense) g.gidx[off] = goff;
     if constexpr (K > 0) {
-        float *o = g.vary + (size_t)off * (3 * K);
+        float *o = g.vary + (size_t)t * (3 * K);
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
             for (int k = 0; k < K; ++k) o[s * K + k] = in_slot_f(s, ctx[0][k], ctx[1][k], ctx[2][k]);
     }
-    } // owned
-    } // fast path
-    // clipped triangles of the whole draw (listed by k_geom_count): wave q of the grid takes entries
-    // q, q + #waves, ...; one wave per triangle, lanes = candidate vertices
-    const uint32_t nclip = g.cnt->clip_n[g.cslot];
-    if (nclip) {
+    } // emit
+    // the block's clipped inputs, one wave per triangle (lanes = candidate vertices)
+    __syncthreads();
+    const uint32_t ncl = s_ncl;
+    if (ncl) {
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        const uint32_t nwaves = gridDim.x * (GEOM_BLOCK / 64);
-        for (uint32_t e = bid * (GEOM_BLOCK / 64) + (uint32_t)w; e < nclip; e += nwaves) {
-            const uint4 en = g.clip_list[e];
-            const uint32_t ct = en.x, cn = en.y >> 16, cb = ct / GEOM_BLOCK;
-            uint32_t base, gbase = 0;
-            if constexpr (MODE == 2) {
-                const uint32_t grp = cb >> 6, inb = cb & 63u;
-                uint32_t part = 0, part_g = 0;
-                if ((uint32_t)lane < grp) part += g.group_sums[lane * GROUP_PAD];
-                if ((uint32_t)lane + 64u < grp) part += g.group_sums[(lane + 64) * GROUP_PAD];
-                if ((uint32_t)lane < inb) part += g.block_sums[(grp << 6) + lane];
-                base = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(part), 63);
-                if (g.dense) {
-                    if ((uint32_t)lane < grp) part_g += g.group_sums_g[lane * GROUP_PAD];
-                    if ((uint32_t)lane + 64u < grp) part_g += g.group_sums_g[(lane + 64) * GROUP_PAD];
-                    if ((uint32_t)lane < inb) part_g += g.block_sums_g[(grp << 6) + lane];
-                    gbase = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(part_g), 63);
-                }
-            } else {
-                base = g.block_sums[cb];
-            }
-            const uint32_t coff = base + (en.y & 0xFFFFu);
-            const bool ok = MODE != 0 ? coff + cn <= g.cap : g.cnt->n_setup != 0u;
-            if (ok) clip_triangle_wave<VS>(g, u, ct, coff, gbase + en.z, lane, s_cxy[w], s_ckey[w], s_cv[w]);
+        for (uint32_t e = (uint32_t)w; e < ncl; e += GEOM_BLOCK / 64) {
+            const uint32_t en = s_cl[e];
+            clip_triangle_wave<VS>(g, u, bid * GEOM_BLOCK + (en & 255u), fbase + (en >> 8), lane, s_cxy[w], s_ckey[w], s_cv[w]);
         }
     }
+}
+
+// An empty mesh launches no geometry kernel proper: the per-draw bookkeeping alone.
+__global__ void k_geom_empty(GeomArgs g)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) geom_bookkeeping(g);
+}
+
+// Exclusive scan of the draw's block sums (in place: they become Counters::block_prefix), by one workgroup of 1024
+// threads (the extra workgroup of k_bin_seg, or k_geom_scan on its own); publishes n_emit and raises the capacity flag
+// when the draw asked for more fan slots than there are.
+__device__ __forceinline__ void geom_scan(uint32_t *__restrict__ sums, uint32_t nblocks, Counters *cnt, int fslot, uint32_t fan_cap)
+{
+    __shared__ uint32_t s_sw[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < nblocks ? sums[i] : 0u;
+        uint32_t inc = wave_incl_scan(v);
+        if (lane == 63) s_sw[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { uint32_t x = s_sw[k]; if (k < w) wbase += x; tot += x; }
+        uint32_t carry = s_carry;
+        if (i < nblocks) sums[i] = carry + wbase + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cnt->n_emit = s_carry;
+        const uint32_t fans = cnt->fan_cursor[fslot];
+        cnt->need_fans = fans;
+        if (fans > fan_cap) atomicOr(&cnt->overflow, 1u);
+    }
+}
+__global__ __launch_bounds__(1024) void k_geom_scan(uint32_t *sums, uint32_t nblocks, Counters *cnt, int fslot, uint32_t fan_cap)
+{
+    geom_scan(sums, nblocks, cnt, fslot, fan_cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -556,10 +422,16 @@ __device__ __forceinline__ TileRange tiles_of_pbox(const RasterArgs &a, const ui
     return t;
 }
 
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_bin(RasterArgs a)
+// slots of the current draw to walk: the inputs' own slots and the fan slots handed out (frr_device.h)
+__device__ __forceinline__ uint32_t draw_slots(const Counters *cnt, int fslot, uint32_t fan_cap)
 {
-    const uint32_t n = a.cnt->n_setup;
+    return cnt->ntris_draw + min(cnt->fan_cursor[fslot], fan_cap);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bin(RasterArgs a, int fslot, uint32_t fan_cap)
+{
+    const uint32_t n = draw_slots(a.cnt, fslot, fan_cap);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * 4u;
@@ -645,8 +517,11 @@ constexpr int BIN_MAX_G = 256;
 constexpr uint32_t BIN_LDS_MAX_TILES = 36864; // 144 KiB of u32 counters
 
 __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg, int slot,
-                                                    uint32_t stage_cap)
+                                                    uint32_t stage_cap, int fslot, uint32_t fan_cap, uint32_t *block_sums, uint32_t nblocks, int do_scan)
 {
+    // do_scan: the launch's LAST workgroup scans the geometry kernel's block sums instead (the tile kernel's resolve
+    // needs the prefix for triangle ids; here it costs no launch and sits on nobody's critical path)
+    if (do_scan && blockIdx.x == gridDim.x - 1) { geom_scan(block_sums, nblocks, a.cnt, fslot, fan_cap); return; }
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[]; // [ntiles], then the staging records
     // the first stage_cap records of the workgroup's region are collected in LDS in their final order and
     // leave as coalesced full-line stores (a scattered 16-B store is a partial-line write: WRITE_SIZE showed
@@ -654,7 +529,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     uint4 *s_stage = reinterpret_cast<uint4 *>(s_hist + ((ntiles + 3u) & ~3u));
     __shared__ uint32_t s_w[BIN_WG / 64];
     __shared__ uint32_t s_base;
-    const uint32_t g = blockIdx.x, G = gridDim.x;
+    const uint32_t g = blockIdx.x, G = gridDim.x - (uint32_t)do_scan;
     for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) s_hist[t] = 0u;
     if (g == 0 && threadIdx.x == 0) { // the other slot belongs to the previous draw, which has drained
         a.cnt->bin_entries_frame += a.cnt->seg_total[slot ^ 1];
@@ -662,7 +537,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
         a.cnt->ent_cursor[slot ^ 1] = 0u;
     }
     __syncthreads();
-    const uint32_t n = a.cnt->n_setup;
+    const uint32_t n = draw_slots(a.cnt, fslot, fan_cap);
     uint32_t chunk = (n + G - 1) / G;
     chunk = (chunk + 63u) & ~63u;
     const uint32_t lo = min(n, g * chunk), hi = min(n, lo + chunk);

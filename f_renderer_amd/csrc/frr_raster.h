@@ -29,6 +29,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
 }
 
+// ---- order keys <-> slots <-> emission indices of the current draw (frr_device.h: slots and order keys) -------------
+// low half of a pixel key for the triangle at `slot`: order key + 1 (0 = "what was there before this draw")
+__device__ __forceinline__ uint32_t order_id(const Counters *cnt, uint32_t slot)
+{
+    const uint32_t nt = cnt->ntris_draw;
+    return 1u + (slot < nt ? slot << FAN_BITS : cnt->fan_okey[slot - nt]);
+}
+// the slot a winning id of THIS draw names, and the reference's emission index of that triangle within the frame
+__device__ __forceinline__ uint32_t id_slot(const Counters *cnt, uint32_t id)
+{
+    const uint32_t okl = id - 1u, t = okl >> FAN_BITS, f = okl & ((1u << FAN_BITS) - 1u);
+    return f ? cnt->ntris_draw + cnt->fanbase[t] + (f - 1u) : t;
+}
+__device__ __forceinline__ uint32_t id_emission(const Counters *cnt, uint32_t id)
+{
+    const uint32_t okl = id - 1u, t = okl >> FAN_BITS, f = okl & ((1u << FAN_BITS) - 1u);
+    return cnt->tri_base + cnt->block_prefix[t / GEOM_BLOCK] + (cnt->tinfo[t] >> FAN_BITS) + (f ? f - 1u : 0u);
+}
+
 struct TileCtx {
     int tile, lx0, ly0, tw, th, ax0, ay0; // window-local origin, extent, absolute pixel origin
     uint32_t beg, end;
@@ -97,8 +116,6 @@ template <int K, int PS>
 __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUniforms &u, const TileCtx &c,
                                              const unsigned long long *s_key, const float *u8lut = nullptr)
 {
-    const uint32_t tri_base = a.cnt->tri_base;
-    const uint32_t *gidx = a.cnt->gidx; // dense-owned draws: slot -> emission index
     for (int i = threadIdx.x; i < TILE_PX; i += (int)blockDim.x) {
         const int x = i & (TILE - 1), y = i >> 5;
         if (x >= c.tw || y >= c.th) continue;
@@ -109,7 +126,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
             if (id == 0u) { a.depth[pi] = a.clear_depth; a.tri_id[pi] = ~0u; }
         }
         if (id == 0u) continue; // existing depth won (or nothing covered this pixel)
-        const uint32_t t = id - 1u;
+        const uint32_t t = id_slot(a.cnt, id);
         if constexpr (PS == FRR_PS_DEPTH) {
             // depth only: the z key is an invertible image of rhw except that it merges -0.0 with +0.0
             // (and NaNs are not ordered): those two cases are re-evaluated below, everything else is decoded
@@ -117,7 +134,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
             if (dz != 0.0f && dz == dz) {
                 const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
                 a.depth[di] = dz;                                                   // :366
-                a.tri_id[di] = tri_base + (gidx ? gidx[t] : t);
+                a.tri_id[di] = id_emission(a.cnt, id);
                 continue;
             }
         }
@@ -128,7 +145,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
         Frag f = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), r0, r1, r2, cx, cy);
         const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
         a.depth[di] = f.rhw;                                                    // :366
-        a.tri_id[di] = tri_base + (gidx ? gidx[t] : t);
+        a.tri_id[di] = id_emission(a.cnt, id);
         if constexpr (PS != FRR_PS_DEPTH) {
             const float w = recip_exact(f.rhw != 0.0f ? f.rhw : 1.0f);          // :368 (== 1.0f / x, bit for bit)
             const float c0 = r0 * f.a * w, c1 = r1 * f.b * w, c2 = r2 * f.c * w; // :370-372
@@ -153,8 +170,6 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
 // groups with a pixel nobody won take scalar stores; keys that merge -0.0 / NaN (see tile_resolve) are re-evaluated.
 __device__ __forceinline__ void tile_resolve_depth4(const RasterArgs &a, const TileCtx &c, const unsigned long long *s_key)
 {
-    const uint32_t tri_base = a.cnt->tri_base;
-    const uint32_t *gidx = a.cnt->gidx; // dense-owned draws: slot -> emission index
     const bool fused = a.fused_clear != 0;
     for (int g = threadIdx.x; g < TILE_PX / 4; g += (int)blockDim.x) {
         const int y = g >> 3, x = (g & 7) * 4;
@@ -168,13 +183,13 @@ __device__ __forceinline__ void tile_resolve_depth4(const RasterArgs &a, const T
             won[i] = id[i] != 0u && x + i < c.tw;      // (pixels of a partial tile beyond the window hold all-ones keys)
             float dz = zkey_decode(zk[i]);
             if (won[i] && !(dz != 0.0f && dz == dz)) { // -0.0 merged with +0.0, or NaN: the reference arithmetic decides
-                const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + (id[i] - 1u));
+                const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + id_slot(a.cnt, id[i]));
                 const uint4 q1 = rp[1], q2 = rp[2], q3 = rp[3];
                 dz = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y), u2f(q3.z),
                                c.ax0 + x + i, c.ay0 + y).rhw;
             }
             dv[i] = won[i] ? f2u(dz) : f2u(a.clear_depth);                                         // :366
-            iv[i] = won[i] ? tri_base + (gidx ? gidx[id[i] - 1u] : id[i] - 1u) : ~0u;
+            iv[i] = won[i] ? id_emission(a.cnt, id[i]) : ~0u;
         }
         const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
         const size_t ci = (size_t)(c.ly0 + y) * a.cstride + (c.lx0 + x);
@@ -228,7 +243,7 @@ __device__ __forceinline__ void sweep_triangle(const RasterArgs &a, const TileCt
     const float r0 = r->rhw[0], r1 = r->rhw[1], r2 = r->rhw[2];
     // p -> (dx, dy): dy = floor((p + 0.5) / bw) via a 1-ulp reciprocal, exact for p < 1024, bw <= 32
     const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
-    const unsigned long long idlow = (unsigned long long)(t + 1u);
+    const unsigned long long idlow = (unsigned long long)order_id(a.cnt, t);
     for (int p = lane; p < npx; p += 64) {
         const int dy = (int)(((float)p + 0.5f) * inv_bw);
         const int dx = p - __mul24(dy, bw);
@@ -693,9 +708,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             const int A01 = -(p1y - p0y), B01 = p1x - p0x;
             const int A12 = -(p2y - p1y), B12 = p2x - p1x;
             const int A20 = -(p0y - p2y), B20 = p0x - p2x;
-            const int e01 = A01 * (bx0 - p0x) + B01 * (by0 - p0y);   // at the bbox-in-tile origin
-            const int e12 = A12 * (bx0 - p1x) + B12 * (by0 - p1y);
-            const int e20 = A20 * (bx0 - p2x) + B20 * (by0 - p2y);
+            // at the bbox-in-tile origin; every factor of a `safe` triangle is below 2^15: 24-bit multiplies are exact
+            const int e01 = __mul24(A01, bx0 - p0x) + __mul24(B01, by0 - p0y);
+            const int e12 = __mul24(A12, bx0 - p1x) + __mul24(B12, by0 - p1y);
+            const int e20 = __mul24(A20, bx0 - p2x) + __mul24(B20, by0 - p2y);
             // accept E > thr, thr = -1 for top-left edges, else 0 (:333-341): a row needs A*dx >= (thr + 1 - E_row)
             SpanTri t;
             t.n01 = (int)((q3.w >> 1) & 1u) - e01;
@@ -713,7 +729,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             s_tri[w][trank] = t;
             s_fa[w][trank] = make_float4(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y));
             s_fb[w][trank] = make_float4(u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y));
-            s_fc[w][trank] = make_float2(u2f(q3.z), u2f(en.x + 1u));
+            s_fc[w][trank] = make_float2(u2f(q3.z), u2f(order_id(a.cnt, en.x)));
         }
         // rows of all survivors laid end to end: heads mark where each triangle's rows start
         const uint32_t rincl = wave_incl_scan_dpp(rows);

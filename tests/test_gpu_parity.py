@@ -244,16 +244,13 @@ def test_window_errors(oracle):
     r.sync()
 
 
-@pytest.mark.parametrize("geom", ["default", "nodense", "scan"])
 @pytest.mark.parametrize("blocked", [False, True])
-def test_tile_partition_stitch(oracle, blocked, geom, monkeypatch):
+def test_tile_partition_stitch(oracle, blocked):
     """Screen-tile partition (multi-GPU scheme): rank r of G renders tile rows ty % G == r (interleaved) or
     the contiguous rows [r*k, (r+1)*k), k = ceil(rows/G) (blocked); the union of the G partial images must
     be byte-identical to the 1-GPU image."""
     import f_renderer_amd as fr
     from f_renderer_amd import scenes
-    if geom != "default":
-        monkeypatch.setenv("FRR_GEOM", geom)   # nodense / scan: every triangle keeps a setup slot on every rank
     W, H, G = 300, 200, 3
     tris = scenes.random_clip_triangles(6000, W, H, seed=41, spread=1.1)
     full = fr.Renderer(W, H)

@@ -1,17 +1,14 @@
-"""Alternate kernel paths kept as fallbacks must produce the same bits as the defaults: FRR_GEOM=scan
-(k_scan_blocks between count and emit, the path of meshes with more than 8192 count blocks)."""
+"""Kernel paths and per-draw state: many geometry blocks with dropped and clipped inputs, repeated and mixed draws,
+every shape of the tile kernel, the fan region's capacity growth."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("geom", ["scan", "default"])
-def test_geometry_paths_agree_with_oracle(oracle, geom, monkeypatch):
+def test_geometry_paths_agree_with_oracle(oracle):
     import f_renderer_amd as fr
     from f_renderer_amd import scenes
-    if geom != "default":
-        monkeypatch.setenv("FRR_GEOM", geom)
     W, H, n = 400, 300, 70000          # many 256-triangle blocks, dropped (w == 0) and clipped triangles
     tris = scenes.random_clip_triangles(n, W, H, seed=9, spread=1.2)
     tris[::97, 1, 3] = 0.0             # w == 0 on one vertex: triangle dropped (renderer.rs:117-119)
@@ -32,13 +29,10 @@ def test_geometry_paths_agree_with_oracle(oracle, geom, monkeypatch):
     assert r.stats()["tris_setup"] == f.counters.tris_setup
 
 
-@pytest.mark.parametrize("geom", ["scan", "default"])
-def test_repeated_draws_per_draw_state_resets(oracle, monkeypatch, geom):
-    """Group sums, the clipped-triangle list and the binning counters alternate slots per draw."""
+def test_repeated_draws_per_draw_state_resets(oracle):
+    """The fan cursor and the binning counters alternate slots per draw."""
     import f_renderer_amd as fr
     from f_renderer_amd import scenes
-    if geom != "default":
-        monkeypatch.setenv("FRR_GEOM", geom)
     W, H = 256, 144
     a = scenes.random_clip_triangles(9000, W, H, seed=12)
     b = scenes.random_clip_triangles(3000, W, H, seed=13, spread=1.3)
@@ -106,10 +100,9 @@ def test_tile_kernel_shapes_agree_with_oracle(oracle, monkeypatch, nw, occ, scen
 
 
 def test_mixed_geometry_paths_across_draws(oracle):
-    """The per-draw slots (group sums, clipped-triangle counter) alternate per draw whichever path a draw takes:
-    self-summing emit (<= 8192 count blocks), k_scan_blocks (more than 2,097,152 triangles) and the empty mesh must
-    each leave the other slot clean for the draw after them -- small -> 2.2M triangles -> small, over two frames,
-    then small -> empty -> small with clipped triangles."""
+    """The per-draw slot (fan cursor) alternates per draw whichever path a draw takes: a small mesh, 2.2M triangles
+    (more than 8192 geometry blocks) and the empty mesh must each leave the other slot clean for the draw after them
+    -- small -> 2.2M triangles -> small, over two frames, then small -> empty -> small with clipped triangles."""
     import f_renderer_amd as fr
     from f_renderer_amd import scenes
     W, H = 256, 144
@@ -179,3 +172,32 @@ def test_filtered_setup_list_is_not_reused(oracle):
         full_t[mask] = t[mask]
     np.testing.assert_array_equal(full_t, f.tri_id)
     np.testing.assert_array_equal(full_d.view(np.uint32), f.depth.view(np.uint32))
+
+
+def test_fan_capacity_overflow_is_reported_then_recovers(oracle):
+    """A mesh whose clipped inputs need more fan slots than the first guess (max(one per input + 4096, min(19 per
+    input, 2^20))): the frame is flagged (FRR_ERR_CAPACITY), the capacity grown, the re-issued frame equals the oracle's."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H, n = 64, 48, 300000
+    tris = scenes.random_clip_triangles(n, 2 * W, 2 * H, seed=51, spread=0.2)
+    tris[..., :2] *= 40.0            # every triangle straddles the frustum: ~4 fan triangles per input
+    f = oracle.Frame(W, H)
+    f.clear()
+    f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
+    if f.counters.frag_nan:
+        pytest.skip("NaN rhw in this scene")
+    assert f.counters.tris_setup > (1 << 20) + 100000
+    r = fr.Renderer(W, H)
+    m = r.upload_mesh(tris, fr.VS_CLIP)
+    r.clear()
+    r.draw(m, fr.PS_DEPTH)
+    with pytest.raises(fr.FrrError) as e:
+        r.sync()
+    assert e.value.code == fr.FRR_ERR_CAPACITY
+    r.clear()
+    r.draw(m, fr.PS_DEPTH)
+    _, d, t = r.readback()
+    np.testing.assert_array_equal(t, f.tri_id)
+    np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+    assert r.stats()["tris_setup"] == f.counters.tris_setup

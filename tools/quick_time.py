@@ -29,6 +29,6 @@ print(f"{W}x{H} n={n}: frame {ms:.3f} ms  -> {n/ms/1e3:.1f} Mtri/s, {st['frag_co
 r.profile_enable(True); r.profile_reset()
 for _ in range(K):
     r.clear(); r.draw(m, fr.PS_DEPTH)
-for k in ["k_clear","k_geom_count","k_scan_blocks","k_geom_emit","k_bin_count","k_bin_seg","k_tile_scan","k_bin_fill","k_raster"]:
+for k in fr.Renderer.KERNELS:
     t, c = r.profile_get(k)
     print(f"  {k:18s} {t/max(c,1)*1e3:9.1f} us  x{c}")

@@ -18,3 +18,8 @@ print("sync ok", flush=True)
 _, d, t = r.readback()
 f = cref.Frame(W, H); f.clear(); f.draw(tris, cref.VS_CLIP, cref.PS_DEPTH, cref.make_uniforms())
 print("ids equal", np.array_equal(t, f.tri_id), "depth equal", np.array_equal(d.view(np.uint32), f.depth.view(np.uint32)), flush=True)
+print("stats", r.stats(), f.counters.as_dict())
+bad = np.nonzero(t != f.tri_id)[0]
+print("bad ids", bad.size, [(int(i), int(t[i]), int(f.tri_id[i])) for i in bad[:12]])
+bd = np.nonzero(d.view(np.uint32) != f.depth.view(np.uint32))[0]
+print("bad depth", bd.size, [(int(i), float(d[i]), float(f.depth[i])) for i in bd[:8]])
