@@ -207,6 +207,7 @@ int check_frame_counters(frr_ctx *c, Counters *host)
         if (h.overflow & 1u) c->fan_hint = (size_t)h.need_fans + h.need_fans / 8 + 1024;
         return fail(c, FRR_ERR_CAPACITY, "device work list overflowed; capacity grown, re-issue the frame");
     }
+    if (h.frag_nan) { c->err = "the frame contained NaN-depth fragments: pixels they cover may differ from the reference (renderer.rs:363-366)"; return FRR_WARN_NAN; }
     return FRR_OK;
 }
 
@@ -624,7 +625,7 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     if (ntris_setup) {
         if ((rc = scan_now(c)) != FRR_OK) return rc;
         Counters h;
-        if ((rc = check_frame_counters(c, &h)) != FRR_OK) return rc;
+        if ((rc = check_frame_counters(c, &h)) < FRR_OK) return rc;
         *ntris_setup = h.n_emit;
     }
     return FRR_OK;
@@ -693,9 +694,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     const int owned_rows = a.rpr > 0 ? std::max(0, std::min(a.tiles_y, (a.rank + 1) * a.rpr) - a.rank * a.rpr)
                                      : (a.tiles_y > a.rank ? (a.tiles_y - a.rank + a.world - 1) / a.world : 0);
     const uint32_t grid = (uint32_t)a.tiles_x * owned_rows;
-#ifndef FRR_NO_MAGIC
     if (a.tiles_x >= 2 && a.tiles_x < 65536 && grid < 65536u) a.tiles_x_magic = (uint32_t)(0x100000000ull / (uint64_t)a.tiles_x + 1ull);
-#endif
     const SpanShape sh = span_shape(c, grid, c->geom_ntris);
     if (ntiles <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep) {
         // segmented LDS multi-split (one launch, no per-entry global atomics): G chunk workgroups, ~3K triangles each
@@ -703,6 +702,10 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + BIN_WG - 1) / BIN_WG, 1), BIN_MAX_G);
         if (c->bin_g > 0) G = (uint32_t)std::min(c->bin_g, BIN_MAX_G);
         G = std::min<uint32_t>(G, (uint32_t)sh.nw * 64u); // the tile kernel reads one segment per thread
+        // (+ one workgroup that scans the geometry kernel's block sums, unless an earlier launch has; a binning workgroup
+        // fills a CU's LDS, so the launch stays within 256 workgroups: a 257th would wait for a whole one to finish)
+        const int do_scan = c->scan_pending ? 1 : 0;
+        if (do_scan && G > 255u) G = 255u;
         if ((rc = ensure(c, c->bin_matrix, c->bin_matrix_cap, (size_t)BIN_MAX_G * ((size_t)c->max_tiles + 1))) != FRR_OK) return rc;
         // dynamic LDS: tile counters + as many staged 16-B records as fit (a chunk emits ~1.8 records per triangle)
         constexpr size_t kLdsBudget = 160 * 1024 - 1024; // the kernel's static LDS is < 1 KB
@@ -723,8 +726,6 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xBFFFFFFFu);
         if ((rc = ensure(c, c->bins2, c->bin2_cap, (size_t)ntiles * S + a.bin_cap)) != FRR_OK) return rc;
         a.bins2 = c->bins2;
-        // (+ one workgroup that scans the geometry kernel's block sums, unless an earlier launch has)
-        const int do_scan = c->scan_pending ? 1 : 0;
         { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G + do_scan), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix, a.slot, stage_cap,
                                                           c->geom_slot, c->geom_fan_cap, c->block_sums, c->geom_nblocks, do_scan); }
         c->scan_pending = false;
@@ -791,10 +792,10 @@ int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uin
         return fail(c, FRR_ERR_INVALID, "the setup list of a partitioned frr_draw holds only this rank's triangles; use frr_geometry to read back the full Vec<[Vertex;3]>");
     { int rcs = settle(c); if (rcs != FRR_OK) return rcs; }
     Counters h;
-    int rc = check_frame_counters(c, &h);
-    if (rc != FRR_OK) return rc;
+    const int rc_frame = check_frame_counters(c, &h);   // (FRR_WARN_NAN is passed on with the data)
+    if (rc_frame < FRR_OK) return rc_frame;
     *ntris = h.n_emit;
-    if (!out) return FRR_OK;
+    if (!out) return rc_frame;
     // the records live at slots (frr_device.h): input t's own slot, or its fan's slots behind the inputs; walking the
     // inputs in order and each fan in order is the reference's emission order
     const uint64_t nt = c->geom_ntris;
@@ -826,7 +827,7 @@ int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uin
             }
         }
     }
-    return FRR_OK;
+    return rc_frame;
 }
 
 int frr_get_stats(frr_ctx *c, frr_stats *out)

@@ -48,6 +48,32 @@ __device__ __forceinline__ uint32_t id_emission(const Counters *cnt, uint32_t id
     return cnt->tri_base + cnt->block_prefix[t / GEOM_BLOCK] + (cnt->tinfo[t] >> FAN_BITS) + (f ? f - 1u : 0u);
 }
 
+// Depth-only draws keep  emission index (within the draw) + 1  in their pixel keys instead of the order key: it is
+// just as monotone, the lookups below are then paid once per surviving triangle of a tile instead of once per pixel,
+// and the resolve adds tri_base.  (Shaded draws need the winner's SLOT per pixel, which only the order key gives.)
+__device__ __forceinline__ uint32_t emission_id(const Counters *cnt, uint32_t slot)
+{
+    const uint32_t nt = cnt->ntris_draw;
+    uint32_t t = slot, q = 0u;
+    if (slot >= nt) { const uint32_t ok = cnt->fan_okey[slot - nt]; t = ok >> FAN_BITS; q = (ok & ((1u << FAN_BITS) - 1u)) - 1u; }
+    return 1u + cnt->block_prefix[t / GEOM_BLOCK] + (cnt->tinfo[t] >> FAN_BITS) + q;
+}
+// the slot of the triangle with emission index e (within the draw): two binary searches; only the depth-only resolve's
+// rare re-evaluation (-0.0 / NaN depths) needs it
+__device__ __forceinline__ uint32_t slot_of_emission(const Counters *cnt, uint32_t e)
+{
+    const uint32_t nt = cnt->ntris_draw, nb = (nt + GEOM_BLOCK - 1) / GEOM_BLOCK;
+    uint32_t lo = 0, hi = nb;                       // last block whose prefix <= e
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (cnt->block_prefix[mid] <= e) lo = mid; else hi = mid; }
+    const uint32_t r = e - cnt->block_prefix[lo];
+    uint32_t a = lo * GEOM_BLOCK, b = min(nt, a + GEOM_BLOCK); // last input of the block whose offset <= r and that emits anything
+    while (b - a > 1u) { const uint32_t mid = (a + b) >> 1; if ((cnt->tinfo[mid] >> FAN_BITS) <= r) a = mid; else b = mid; }
+    // (inputs that emit nothing share their successor's offset: step back to the one that covers r)
+    while ((cnt->tinfo[a] & ((1u << FAN_BITS) - 1u)) == 0u && a > lo * GEOM_BLOCK) --a;
+    const uint32_t ti = cnt->tinfo[a], n = ti & ((1u << FAN_BITS) - 1u), q = r - (ti >> FAN_BITS);
+    return n == 1u ? a : nt + cnt->fanbase[a] + q;
+}
+
 struct TileCtx {
     int tile, lx0, ly0, tw, th, ax0, ay0; // window-local origin, extent, absolute pixel origin
     uint32_t beg, end;
@@ -79,7 +105,6 @@ __device__ __forceinline__ TileCtx tile_ctx(const RasterArgs &a)
 __device__ __forceinline__ void tile_load_keys(const RasterArgs &a, const TileCtx &c, unsigned long long *s_key,
                                                unsigned long long oob = 0ull)
 {
-#ifndef FRR_NO_FASTKEYS
     if (a.fused_clear && c.tw == TILE && c.th == TILE) {
         // a full tile of a draw that carries the frame's clear: one constant, 32 bytes per lane and store
         const uint32_t k = zkey(a.clear_depth);
@@ -87,7 +112,6 @@ __device__ __forceinline__ void tile_load_keys(const RasterArgs &a, const TileCt
         for (int i = threadIdx.x; i < TILE_PX / 2; i += (int)blockDim.x) p[i] = make_uint4(0u, k, 0u, k);
         return;
     }
-#endif
     for (int i = threadIdx.x; i < TILE_PX; i += (int)blockDim.x) {
         const int x = i & (TILE - 1), y = i >> 5;
         unsigned long long k = oob;
@@ -171,6 +195,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
 __device__ __forceinline__ void tile_resolve_depth4(const RasterArgs &a, const TileCtx &c, const unsigned long long *s_key)
 {
     const bool fused = a.fused_clear != 0;
+    const uint32_t tri_base = a.cnt->tri_base;      // (the keys of a depth-only draw hold emission indices: emission_id)
     for (int g = threadIdx.x; g < TILE_PX / 4; g += (int)blockDim.x) {
         const int y = g >> 3, x = (g & 7) * 4;
         if (y >= c.th || x >= c.tw) continue;
@@ -183,13 +208,13 @@ __device__ __forceinline__ void tile_resolve_depth4(const RasterArgs &a, const T
             won[i] = id[i] != 0u && x + i < c.tw;      // (pixels of a partial tile beyond the window hold all-ones keys)
             float dz = zkey_decode(zk[i]);
             if (won[i] && !(dz != 0.0f && dz == dz)) { // -0.0 merged with +0.0, or NaN: the reference arithmetic decides
-                const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + id_slot(a.cnt, id[i]));
+                const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + slot_of_emission(a.cnt, id[i] - 1u));
                 const uint4 q1 = rp[1], q2 = rp[2], q3 = rp[3];
                 dz = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y), u2f(q3.z),
                                c.ax0 + x + i, c.ay0 + y).rhw;
             }
             dv[i] = won[i] ? f2u(dz) : f2u(a.clear_depth);                                         // :366
-            iv[i] = won[i] ? id_emission(a.cnt, id[i]) : ~0u;
+            iv[i] = won[i] ? tri_base + (id[i] - 1u) : ~0u;
         }
         const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
         const size_t ci = (size_t)(c.ly0 + y) * a.cstride + (c.lx0 + x);
@@ -216,7 +241,7 @@ __device__ __forceinline__ void tile_resolve_depth4(const RasterArgs &a, const T
 
 // Brute-force sweep of ONE triangle (wave-uniform index t) by the whole wave: every pixel of
 // bbox-in-tile is tested with the wrapping-i32 edge functions of renderer.rs:329-341.
-__device__ __forceinline__ void sweep_triangle(const RasterArgs &a, const TileCtx &c, uint32_t t, int lane,
+__device__ __forceinline__ void sweep_triangle(const RasterArgs &a, const TileCtx &c, uint32_t t, uint32_t key_id, int lane,
                                                unsigned long long *s_key, uint32_t &n_cov, uint32_t &n_nan)
 {
     const RasterRec *__restrict__ r = a.recs + t;
@@ -243,7 +268,7 @@ __device__ __forceinline__ void sweep_triangle(const RasterArgs &a, const TileCt
     const float r0 = r->rhw[0], r1 = r->rhw[1], r2 = r->rhw[2];
     // p -> (dx, dy): dy = floor((p + 0.5) / bw) via a 1-ulp reciprocal, exact for p < 1024, bw <= 32
     const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
-    const unsigned long long idlow = (unsigned long long)order_id(a.cnt, t);
+    const unsigned long long idlow = (unsigned long long)key_id;
     for (int p = lane; p < npx; p += 64) {
         const int dy = (int)(((float)p + 0.5f) * inv_bw);
         const int dx = p - __mul24(dy, bw);
@@ -281,7 +306,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
     uint32_t n_cov = 0, n_nan = 0;
     for (uint32_t e = c.beg + wave; e < c.end; e += 4) {
         const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e].x);
-        sweep_triangle(a, c, t, lane, s_key, n_cov, n_nan);
+        sweep_triangle(a, c, t, order_id(a.cnt, t), lane, s_key, n_cov, n_nan);
     }
     if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
     if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
@@ -692,7 +717,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             um &= um - 1;
             const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)en.x, src);
             uint32_t ncv = 0;
-            sweep_triangle(a, c, tu, lane, s_key, ncv, n_nan);
+            sweep_triangle(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(a.cnt, tu) : order_id(a.cnt, tu), lane, s_key, ncv, n_nan);
             n_cov += ncv;
         }
         const unsigned long long am = __ballot(alive);
@@ -729,7 +754,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             s_tri[w][trank] = t;
             s_fa[w][trank] = make_float4(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y));
             s_fb[w][trank] = make_float4(u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y));
-            s_fc[w][trank] = make_float2(u2f(q3.z), u2f(order_id(a.cnt, en.x)));
+            s_fc[w][trank] = make_float2(u2f(q3.z), u2f(PS == FRR_PS_DEPTH ? emission_id(a.cnt, en.x) : order_id(a.cnt, en.x)));
         }
         // rows of all survivors laid end to end: heads mark where each triangle's rows start
         const uint32_t rincl = wave_incl_scan_dpp(rows);
@@ -866,11 +891,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
     if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
     __syncthreads();
     FRR_T(6);
-#ifndef FRR_NO_DEPTH4
     if constexpr (PS == FRR_PS_DEPTH) tile_resolve_depth4(a, c, s_key);
-    else
-#endif
-    tile_resolve<K, PS>(a, u, c, s_key, TEXTURED ? s_u8 : nullptr);
+    else tile_resolve<K, PS>(a, u, c, s_key, TEXTURED ? s_u8 : nullptr);
 #ifdef FRR_DEBUG_COUNTERS
     FRR_T(7);
     if (lane == 0) {

@@ -324,7 +324,11 @@ public:
     frr_ctx *raw() { return ctx_; }
 
 private:
-    void check(int rc) { if (rc != FRR_OK) throw Error(rc, frr_last_error(ctx_)); }
+    // negative status: throw; FRR_WARN_NAN (positive): results were delivered, remembered in last_warning
+    void check(int rc) { if (rc < FRR_OK) throw Error(rc, frr_last_error(ctx_)); last_warning = rc; }
+public:
+    int last_warning = FRR_OK;
+private:
     frr_ctx *ctx_ = nullptr;
     uint32_t width_, height_;
 };

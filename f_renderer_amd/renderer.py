@@ -134,6 +134,7 @@ class Renderer:
         self.uniforms.specular_strength = 0.5
         self.uniforms.flat_color[:] = [1.0, 1.0, 1.0, 1.0]
         self._keep = []
+        self.last_warning = None
 
     # -- lifetime / errors --
     def close(self):
@@ -148,8 +149,11 @@ class Renderer:
             pass
 
     def _check(self, rc):
-        if rc != N.FRR_OK:
+        """Negative status: raise.  Positive status (FRR_WARN_NAN): the call delivered its results; remembered in
+        `last_warning` (None when the latest checked call had nothing to report)."""
+        if rc < N.FRR_OK:
             raise FrrError(rc, self._lib.frr_last_error(self._ctx).decode())
+        self.last_warning = rc if rc > N.FRR_OK else None
 
     # -- scene --
     def upload_mesh(self, vs_inputs, vs_id):

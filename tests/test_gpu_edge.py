@@ -304,3 +304,41 @@ def test_owned_rows_are_what_a_partitioned_draw_writes(oracle, world, blocked):
     np.testing.assert_array_equal(got_t, f.tri_id)
     np.testing.assert_array_equal(got_d.view(np.uint32), f.depth.view(np.uint32))
     assert r.owned_rows((0, 0)) == []
+
+
+def test_nan_depth_fragments_are_reported(oracle):
+    """renderer.rs:363-366: a fragment whose 1/w interpolates to NaN always passes the depth test and the next fragment
+    on that pixel then passes too.  The tile kernels do not reproduce that order dependence; they count such fragments
+    and frr_readback / frr_sync return FRR_WARN_NAN with the (complete) frame, so a caller cannot miss it.  The scene: a
+    screen-filling quad, a clipped triangle with a vertex at x = 3e38 (its screen position overflows to inf, so every
+    fragment of its fan interpolates inf * 0), and a nearer triangle on top."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H = 160, 120
+    tris = np.array([
+        [(-0.9, -0.9, 0.5, 1), (0.9, -0.9, 0.5, 1), (0.9, 0.9, 0.5, 1)],
+        [(-0.9, -0.9, 0.5, 1), (0.9, 0.9, 0.5, 1), (-0.9, 0.9, 0.5, 1)],
+        [(3e38, 0.2, 0.5, 1), (-0.5, -0.5, 0.5, 1), (-0.5, 0.6, 0.5, 1)],
+        [(-0.3, -0.3, 1.0, 2), (0.7, -0.3, 1.0, 2), (0.2, 0.8, 1.0, 2)],
+    ], np.float32)
+    f = oracle.Frame(W, H)
+    f.clear()
+    f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
+    assert f.counters.frag_nan > 0
+    r = fr.Renderer(W, H)
+    r.clear()
+    r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
+    _, d, t = r.readback()
+    assert r.last_warning == fr.FRR_WARN_NAN
+    st = r.stats()
+    assert st["frag_nan"] > 0 and st["tris_setup"] == f.counters.tris_setup and st["frag_covered"] == f.counters.frag_covered
+    r.sync()
+    assert r.last_warning == fr.FRR_WARN_NAN
+    same = (t == f.tri_id) & (d.view(np.uint32) == f.depth.view(np.uint32))
+    assert same.mean() > 0.5        # only pixels a NaN fragment covers may differ
+    # a clean frame afterwards reports nothing
+    good = scenes.random_clip_triangles(500, W, H, seed=5)
+    r.clear()
+    r.draw(r.upload_mesh(good, fr.VS_CLIP), fr.PS_DEPTH)
+    r.readback()
+    assert r.last_warning is None
