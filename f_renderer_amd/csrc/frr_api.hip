@@ -696,7 +696,8 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     const uint32_t grid = (uint32_t)a.tiles_x * owned_rows;
     if (a.tiles_x >= 2 && a.tiles_x < 65536 && grid < 65536u) a.tiles_x_magic = (uint32_t)(0x100000000ull / (uint64_t)a.tiles_x + 1ull);
     const SpanShape sh = span_shape(c, grid, c->geom_ntris);
-    if (ntiles <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep) {
+    if (grid <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep) {
+        const uint32_t ltiles = std::max<uint32_t>(grid, 1u);   // the binning numbers the rank's OWN tiles only (local_tile_row)
         // segmented LDS multi-split (one launch, no per-entry global atomics): G chunk workgroups, ~3K triangles each
         // (small meshes: one triangle per thread, so that the launch is not three workgroups doing all the work)
         uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + BIN_WG - 1) / BIN_WG, 1), BIN_MAX_G);
@@ -709,7 +710,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         if ((rc = ensure(c, c->bin_matrix, c->bin_matrix_cap, (size_t)BIN_MAX_G * ((size_t)c->max_tiles + 1))) != FRR_OK) return rc;
         // dynamic LDS: tile counters + as many staged 16-B records as fit (a chunk emits ~1.8 records per triangle)
         constexpr size_t kLdsBudget = 160 * 1024 - 1024; // the kernel's static LDS is < 1 KB
-        const size_t hist_bytes = (((size_t)ntiles + 3) & ~(size_t)3) * sizeof(uint32_t);
+        const size_t hist_bytes = (((size_t)ltiles + 3) & ~(size_t)3) * sizeof(uint32_t);
         const uint32_t stage_cap = (uint32_t)std::min<size_t>((kLdsBudget - hist_bytes) / 16, 9216);
         const size_t lds = hist_bytes + (size_t)stage_cap * 16;
         if (!c->lds_attr_set) {
@@ -719,14 +720,14 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         c->bin_slot ^= 1;
         a.seg = c->bin_matrix; a.nseg = G; a.slot = c->bin_slot;
         // near-first copies (bins2): a fixed slot per tile, 8x the mean tile load, + an overflow arena of bin_cap records
-        uint64_t S = std::max<uint64_t>(256, (c->geom_ntris * 16 + ntiles - 1) / ntiles);
-        S = std::min<uint64_t>(S, ((uint64_t)1 << 30) / ntiles);
+        uint64_t S = std::max<uint64_t>(256, (c->geom_ntris * 16 + ntiles - 1) / ntiles);   // (per-tile load of the whole window: ownership does not change it)
+        S = std::min<uint64_t>(S, ((uint64_t)1 << 30) / ltiles);
         if (c->ent_slot_override) S = c->ent_slot_override;
         a.ent_slot = (uint32_t)S;
         a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xBFFFFFFFu);
-        if ((rc = ensure(c, c->bins2, c->bin2_cap, (size_t)ntiles * S + a.bin_cap)) != FRR_OK) return rc;
+        if ((rc = ensure(c, c->bins2, c->bin2_cap, (size_t)ltiles * S + a.bin_cap)) != FRR_OK) return rc;
         a.bins2 = c->bins2;
-        { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G + do_scan), dim3(BIN_WG), lds, c->stream, a, ntiles, c->bin_matrix, a.slot, stage_cap,
+        { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G + do_scan), dim3(BIN_WG), lds, c->stream, a, ltiles, c->bin_matrix, a.slot, stage_cap,
                                                           c->geom_slot, c->geom_fan_cap, c->block_sums, c->geom_nblocks, do_scan); }
         c->scan_pending = false;
     } else {

@@ -143,6 +143,16 @@ __device__ __forceinline__ bool owns_tile_row(int ty, int rank, int world, int r
     return world <= 1 || (rpr > 0 ? ty / rpr == rank : ty % world == rank);
 }
 
+// Index of an OWNED tile row among the rank's rows (0, 1, 2 ...): the segmented binning and the tile kernel number a
+// rank's tiles row-major over its own rows only, so that a rank of N keeps 1/N of the tile counters, segment-table
+// columns and near-first slots.  (Rows the rank does not own may map anywhere: callers test ownership first.)
+__device__ __forceinline__ int local_tile_row(int ty, int rank, int world, int rpr)
+{
+    if (world <= 1) return ty;
+    if (rpr > 0) return ty - rank * rpr;
+    return (int)(((float)ty + 0.5f) * (1.0f / (float)world)); // ty / world: exact for tile rows (< 2^11)
+}
+
 // what frr_clear does to the counters (by k_clear, or deferred to the next draw's bookkeeping thread)
 __device__ __forceinline__ void reset_frame_counters(Counters *cnt)
 {

@@ -508,6 +508,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(RasterArgs a, uint32_t ntile
 //      private, contiguous, tile-sorted region;
 //   3. publishes the row seg[g][0..ntiles] = those starts (+ the end sentinel);
 //   4. walks the chunk again (L2-hot) and scatters the 16-byte cull records with returning LDS atomics.
+// Tiles are numbered over the rank's OWN tile rows (local_tile_row), so `ntiles` is what the rank owns.
 // The tile kernel reads column t of `seg` (G (start,end) pairs) and walks the segments; no column
 // scan, no CSR scan and no second launch are needed.  The global-atomic CSR path (k_bin above) remains
 // as the fallback when the tile count does not fit LDS.
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
                 const int nt = ntx * nty;
                 auto visit = [&](const uint4 &ent, int tx, int ty) {
                     if (!owns_tile_row(ty, a.rank, a.world, a.rpr)) return;
-                    const int tile = ty * a.tiles_x + tx;
+                    const int tile = local_tile_row(ty, a.rank, a.world, a.rpr) * a.tiles_x + tx;
                     if constexpr (SCATTER) {
                         put(atomicAdd(&s_hist[tile], 1u), ent);
                     } else {
@@ -585,20 +586,21 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
                 if (small) {
                     const bool own0 = owns_tile_row(t.ty0, a.rank, a.world, a.rpr);
                     const bool own1 = nty == 2 && owns_tile_row(t.ty0 + 1, a.rank, a.world, a.rpr);
-                    const int t00 = t.ty0 * a.tiles_x + t.tx0;
+                    const int t00 = local_tile_row(t.ty0, a.rank, a.world, a.rpr) * a.tiles_x + t.tx0;
+                    const int t10 = local_tile_row(t.ty0 + 1, a.rank, a.world, a.rpr) * a.tiles_x + t.tx0;
                     const bool v0 = own0, v1 = own0 && ntx == 2, v2 = own1, v3 = own1 && ntx == 2;
                     if constexpr (SCATTER) {
                         uint32_t p0 = ~0u, p1 = ~0u, p2 = ~0u, p3 = ~0u;
                         if (v0) p0 = atomicAdd(&s_hist[t00], 1u);
                         if (v1) p1 = atomicAdd(&s_hist[t00 + 1], 1u);
-                        if (v2) p2 = atomicAdd(&s_hist[t00 + a.tiles_x], 1u);
-                        if (v3) p3 = atomicAdd(&s_hist[t00 + a.tiles_x + 1], 1u);
+                        if (v2) p2 = atomicAdd(&s_hist[t10], 1u);
+                        if (v3) p3 = atomicAdd(&s_hist[t10 + 1], 1u);
                         put(p0, mine); put(p1, mine); put(p2, mine); put(p3, mine);
                     } else {
                         if (v0) atomicAdd(&s_hist[t00], 1u);
                         if (v1) atomicAdd(&s_hist[t00 + 1], 1u);
-                        if (v2) atomicAdd(&s_hist[t00 + a.tiles_x], 1u);
-                        if (v3) atomicAdd(&s_hist[t00 + a.tiles_x + 1], 1u);
+                        if (v2) atomicAdd(&s_hist[t10], 1u);
+                        if (v3) atomicAdd(&s_hist[t10 + 1], 1u);
                     }
                 }
                 // footprints up to 3x3 tiles, same idea (nine predicated positions); skipped by waves without any
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
 #pragma unroll
                         for (int dx = 0; dx < 3; ++dx) {
                             const bool v = own && dx < ntx;
-                            const int tile = (t.ty0 + dy) * a.tiles_x + t.tx0 + dx;
+                            const int tile = local_tile_row(t.ty0 + dy, a.rank, a.world, a.rpr) * a.tiles_x + t.tx0 + dx;
                             pos[dy * 3 + dx] = ~0u;
                             if constexpr (SCATTER) { if (v) pos[dy * 3 + dx] = atomicAdd(&s_hist[tile], 1u); }
                             else { if (v) atomicAdd(&s_hist[tile], 1u); }

@@ -75,7 +75,7 @@ __device__ __forceinline__ uint32_t slot_of_emission(const Counters *cnt, uint32
 }
 
 struct TileCtx {
-    int tile, lx0, ly0, tw, th, ax0, ay0; // window-local origin, extent, absolute pixel origin
+    int tile, ltile, lx0, ly0, tw, th, ax0, ay0; // tile index in the window / among the rank's own tiles; window-local origin, extent, absolute pixel origin
     uint32_t beg, end;
 };
 
@@ -88,6 +88,7 @@ __device__ __forceinline__ TileCtx tile_ctx(const RasterArgs &a)
     const int tx = bid - trow * a.tiles_x;
     const int ty = a.rpr > 0 ? a.rank * a.rpr + trow : a.rank + trow * a.world;
     c.tile = ty * a.tiles_x + tx;
+    c.ltile = bid;                                      // its index among the rank's own tiles (segmented binning)
     c.lx0 = tx * TILE; c.ly0 = ty * TILE;
     c.tw = min(TILE, a.win_w - c.lx0); c.th = min(TILE, a.win_h - c.ly0);
     c.ax0 = a.x0 + c.lx0; c.ay0 = a.y0 + c.ly0;
@@ -517,10 +518,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
     TileCtx c = tile_ctx(a);
     const bool segmented = a.nseg != 0;
     if (segmented) {
-        // column c.tile of the segment table: (start, end) of this tile's records in each chunk's region
+        // column c.ltile of the segment table: (start, end) of this tile's records in each chunk's region
         uint32_t s0 = 0, cn = 0;
         if (threadIdx.x < a.nseg) {
-            const uint32_t *r = a.seg + (size_t)threadIdx.x * ((size_t)a.tiles_x * a.tiles_y + 1) + c.tile;
+            const uint32_t *r = a.seg + (size_t)threadIdx.x * ((size_t)gridDim.x + 1) + c.ltile;   // (grid = the rank's tiles)
             s0 = r[0];
             cn = r[1] - s0;
         }
@@ -541,8 +542,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             // where this tile's near-first copy goes: its own fixed slot of bins2, or -- a tile hotter than
             // the slot -- space from the shared overflow arena behind the slots.  (One atomic per tile on a
             // single address costs ~17 ns each, serialised across the whole launch; hence the slots.)
-            const uint32_t ntiles = (uint32_t)(a.tiles_x * a.tiles_y);
-            s_ebase = total <= a.ent_slot ? (uint32_t)c.tile * a.ent_slot
+            const uint32_t ntiles = gridDim.x;
+            s_ebase = total <= a.ent_slot ? (uint32_t)c.ltile * a.ent_slot
                                           : ntiles * a.ent_slot + atomicAdd(&a.cnt->ent_cursor[a.slot], total);
         }
         __syncthreads();
