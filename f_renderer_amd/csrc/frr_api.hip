@@ -231,9 +231,10 @@ int scan_now(frr_ctx *c)
 // budgeted for).  Measured on the 1080p / 4096^2 / 4K frames (profiles/, tools/exp_shapes.py): a CU is issue-bound with
 // six 4-wave workgroups, so budgeting registers for eight buys nothing; wider workgroups shorten a tile's chain and win
 // when the tiles do not fill the chip (a partitioned rank, a small window); three waves per tile win when there are
-// many lightly loaded tiles (about 120 records each on the 4096^2 frame: four waves would cull 30 records apiece).
+// many lightly loaded tiles of a depth-only draw (about 120 records each on the 4096^2 frame: four waves would cull 30
+// records apiece); shaded draws keep four (the resolve is most of their work: 55 vs 88 us on the 69k-triangle sphere).
 struct SpanShape { int nw, occ; };
-SpanShape span_shape(const frr_ctx *c, uint32_t grid, uint64_t ntris)
+SpanShape span_shape(const frr_ctx *c, uint32_t grid, uint64_t ntris, int ps_id)
 {
     static const SpanShape all[] = {{16, 4}, {8, 6}, {6, 6}, {4, 8}, {4, 6}, {3, 6}};
     if (c->raster_nw || c->raster_occ)                   // FRR_RASTER_NW / FRR_RASTER_OCC (tests, tools)
@@ -241,7 +242,7 @@ SpanShape span_shape(const frr_ctx *c, uint32_t grid, uint64_t ntris)
             if ((!c->raster_nw || k.nw == c->raster_nw) && (!c->raster_occ || k.occ == c->raster_occ)) return k;
     if (grid <= 256u) return {16, 4};
     if (grid <= 768u) return {8, 6};
-    if (grid > 1536u && ntris * 2u <= 192ull * grid) return {3, 6};
+    if (ps_id == FRR_PS_DEPTH && grid > 1536u && ntris * 2u <= 192ull * grid) return {3, 6};
     return {4, 6};
 }
 
@@ -695,7 +696,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
                                      : (a.tiles_y > a.rank ? (a.tiles_y - a.rank + a.world - 1) / a.world : 0);
     const uint32_t grid = (uint32_t)a.tiles_x * owned_rows;
     if (a.tiles_x >= 2 && a.tiles_x < 65536 && grid < 65536u) a.tiles_x_magic = (uint32_t)(0x100000000ull / (uint64_t)a.tiles_x + 1ull);
-    const SpanShape sh = span_shape(c, grid, c->geom_ntris);
+    const SpanShape sh = span_shape(c, grid, c->geom_ntris, ps_id);
     if (grid <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep) {
         const uint32_t ltiles = std::max<uint32_t>(grid, 1u);   // the binning numbers the rank's OWN tiles only (local_tile_row)
         // segmented LDS multi-split (one launch, no per-entry global atomics): G chunk workgroups, ~3K triangles each
