@@ -69,6 +69,184 @@ __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t *s_w
     return base + inc - v;
 }
 
+// ---- binning helpers (used by K2 and by the fused geometry + binning kernel) ------------------------------------
+constexpr int BIN_WG = 1024;
+constexpr int BIN_MAX_G = 256;
+constexpr uint32_t BIN_LDS_MAX_TILES = 36864; // 144 KiB of u32 counters
+
+struct TileRange { int tx0, tx1, ty0, ty1; }; // inclusive-exclusive tile ranges (window-local)
+
+
+__device__ __forceinline__ TileRange tiles_of_pbox(const RasterArgs &a, const uint4 b)
+{
+    const int mnx = (int)(short)(b.x & 0xFFFFu), mny = (int)(short)(b.x >> 16);
+    const int mxx = (int)(short)(b.y & 0xFFFFu), mxy = (int)(short)(b.y >> 16);
+    const int minx = clampi(mnx, a.x0, a.x1), maxx = clampi(mxx, a.x0, a.x1);
+    const int miny = clampi(mny, a.y0, a.y1), maxy = clampi(mxy, a.y0, a.y1);
+    TileRange t;
+    if (maxx <= minx || maxy <= miny) { t.tx0 = t.tx1 = t.ty0 = t.ty1 = 0; return t; }
+    t.tx0 = (minx - a.x0) / TILE; t.tx1 = (maxx - 1 - a.x0) / TILE + 1;
+    t.ty0 = (miny - a.y0) / TILE; t.ty1 = (maxy - 1 - a.y0) / TILE + 1;
+    return t;
+}
+
+// where a record goes: the first stage_cap records of the workgroup's region are collected in LDS in their final order
+// and leave as coalesced full-line stores (a scattered 16-B store is a partial-line write: WRITE_SIZE showed 2.3x the
+// bytes); what does not fit goes straight to memory
+struct BinPut {
+    uint4 *s_stage, *bins;
+    uint32_t region, stage_cap, bin_cap;
+    __device__ __forceinline__ void operator()(uint32_t pos, const uint4 &ent) const // pos = ~0u: nothing
+    {
+        const uint32_t local = pos - region;
+        if (pos != ~0u) {
+            if (local < stage_cap) s_stage[local] = ent;
+            else if (pos < bin_cap) bins[pos] = ent;
+        }
+    }
+};
+
+// One binning record per lane (pb = the lane's pbox entry, all zero = nothing; the lanes of a wave hold the consecutive
+// slots base .. base+63): count it (SCATTER = false) or place it (true) in every owned tile its clamped bbox touches.
+// Called by whole waves: large footprints are spread over the lanes.
+template <bool SCATTER>
+__device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, const uint4 pb, uint32_t base, int lane, const BinPut &put)
+{
+    const uint32_t i = base + (uint32_t)lane;
+    const TileRange t = tiles_of_pbox(a, pb);
+    const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
+    const int nt = ntx * nty;
+    auto visit = [&](const uint4 &ent, int tx, int ty) {
+        if (!owns_tile_row(ty, a.rank, a.world, a.rpr)) return;
+        const int tile = local_tile_row(ty, a.rank, a.world, a.rpr) * a.tiles_x + tx;
+        if constexpr (SCATTER) {
+            put(atomicAdd(&s_hist[tile], 1u), ent);
+        } else {
+            atomicAdd(&s_hist[tile], 1u);
+        }
+    };
+    const uint4 mine = make_uint4(i, pb.z, pb.x, pb.y);
+    // footprints of at most 2x2 tiles (the common case) as straight-line code: up to four
+    // independent LDS atomics in flight instead of a loop of dependent atomic -> store steps
+    const bool small = nt > 0 && ntx <= 2 && nty <= 2;
+    if (small) {
+        const bool own0 = owns_tile_row(t.ty0, a.rank, a.world, a.rpr);
+        const bool own1 = nty == 2 && owns_tile_row(t.ty0 + 1, a.rank, a.world, a.rpr);
+        const int t00 = local_tile_row(t.ty0, a.rank, a.world, a.rpr) * a.tiles_x + t.tx0;
+        const int t10 = local_tile_row(t.ty0 + 1, a.rank, a.world, a.rpr) * a.tiles_x + t.tx0;
+        const bool v0 = own0, v1 = own0 && ntx == 2, v2 = own1, v3 = own1 && ntx == 2;
+        if constexpr (SCATTER) {
+            uint32_t p0 = ~0u, p1 = ~0u, p2 = ~0u, p3 = ~0u;
+            if (v0) p0 = atomicAdd(&s_hist[t00], 1u);
+            if (v1) p1 = atomicAdd(&s_hist[t00 + 1], 1u);
+            if (v2) p2 = atomicAdd(&s_hist[t10], 1u);
+            if (v3) p3 = atomicAdd(&s_hist[t10 + 1], 1u);
+            put(p0, mine); put(p1, mine); put(p2, mine); put(p3, mine);
+        } else {
+            if (v0) atomicAdd(&s_hist[t00], 1u);
+            if (v1) atomicAdd(&s_hist[t00 + 1], 1u);
+            if (v2) atomicAdd(&s_hist[t10], 1u);
+            if (v3) atomicAdd(&s_hist[t10 + 1], 1u);
+        }
+    }
+    // footprints up to 3x3 tiles, same idea (nine predicated positions); skipped by waves without any
+    const bool mid = nt > 0 && !small && ntx <= 3 && nty <= 3;
+    if (__ballot(mid)) {
+        uint32_t pos[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const bool own = mid && dy < nty && owns_tile_row(t.ty0 + dy, a.rank, a.world, a.rpr);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const bool v = own && dx < ntx;
+                const int tile = local_tile_row(t.ty0 + dy, a.rank, a.world, a.rpr) * a.tiles_x + t.tx0 + dx;
+                pos[dy * 3 + dx] = ~0u;
+                if constexpr (SCATTER) { if (v) pos[dy * 3 + dx] = atomicAdd(&s_hist[tile], 1u); }
+                else { if (v) atomicAdd(&s_hist[tile], 1u); }
+            }
+        }
+        if constexpr (SCATTER) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) put(pos[q], mine);
+        }
+    }
+    // larger footprints: four at a time, each spread over a quarter of the wave (16 lanes)
+    unsigned long long big = __ballot(nt > 0 && !small && !mid);
+    while (big) {
+        int src = -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sj = big ? __builtin_ctzll(big) : -1;
+            big &= big - 1;                    // (0 stays 0)
+            if ((lane >> 4) == j) src = sj;
+        }
+        const int sl = src < 0 ? 0 : src;
+        const int bx0 = __shfl(t.tx0, sl), by0 = __shfl(t.ty0, sl), bnx = __shfl(ntx, sl);
+        const int bnt_src = __shfl(nt, sl); // unconditional: a cross-lane read must not sit under `src >= 0` (inactive source lanes read as 0)
+        const int bnt = src < 0 ? 0 : bnt_src;
+        const uint4 ent = make_uint4(base + sl, __shfl(pb.z, sl), __shfl(pb.x, sl), __shfl(pb.y, sl));
+        for (int q = lane & 15; q < bnt; q += 16) visit(ent, bx0 + q % bnx, by0 + q / bnx);
+    }
+}
+
+// the slots [lo, hi) of `pbox`, by the waves of a BIN_WG-thread workgroup
+template <bool SCATTER>
+__device__ __forceinline__ void bin_walk(const RasterArgs &a, uint32_t *s_hist, const uint4 *__restrict__ pbox, uint32_t lo, uint32_t hi,
+                                         int lane, uint32_t wave, const BinPut &put)
+{
+    constexpr int PF = 4; // bboxes of PF rounds are fetched up front: the loop is latency-bound otherwise
+    for (uint32_t base0 = lo + wave * 64u; base0 < hi; base0 += PF * BIN_WG) {
+        uint4 pb[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const uint32_t i = base0 + k * BIN_WG + lane;
+            pb[k] = i < hi ? pbox[i] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const uint32_t base = base0 + k * BIN_WG;
+            if (base >= hi) break;
+            bin_one<SCATTER>(a, s_hist, pb[k], base, lane, put);
+        }
+    }
+}
+
+// Exclusive scan of the workgroup's tile histogram in place, ONE global atomic to reserve its region of `bins`, and its
+// row of the segment table; returns the region's first record (bin_cap when the frame overflowed) and its size.
+__device__ __forceinline__ void bin_reserve_publish(const RasterArgs &a, uint32_t *s_hist, uint32_t ntiles, uint32_t *__restrict__ row, int slot,
+                                                    uint32_t *s_w /*[BIN_WG/64]*/, uint32_t *s_base, int lane, uint32_t wave,
+                                                    uint32_t &base_out, uint32_t &total_out)
+{
+    // thread i owns the slice [i*per, (i+1)*per)
+    const uint32_t per = (ntiles + BIN_WG - 1) / BIN_WG;
+    const uint32_t t0 = min(ntiles, threadIdx.x * per), t1 = min(ntiles, t0 + per);
+    uint32_t sum = 0;
+    for (uint32_t t = t0; t < t1; ++t) sum += s_hist[t];
+    const uint32_t inc = wave_incl_scan(sum);
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < BIN_WG / 64; ++k) { const uint32_t x = s_w[k]; if (k < (int)wave) wbase += x; total += x; }
+    if (threadIdx.x == 0) {
+        const unsigned long long b64 = atomicAdd(&a.cnt->seg_total[slot], (unsigned long long)total);
+        uint32_t base = (uint32_t)b64;
+        if (b64 + total > (unsigned long long)a.bin_cap) { atomicOr(&a.cnt->overflow, 2u); base = a.bin_cap; } // frame flagged invalid; nothing of this chunk is stored
+        *s_base = base;
+    }
+    __syncthreads();
+    const uint32_t base = *s_base;
+    {
+        uint32_t run = base + (wbase + inc - sum);
+        for (uint32_t t = t0; t < t1; ++t) { const uint32_t x = s_hist[t]; s_hist[t] = min(run, a.bin_cap); run += x; }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) row[t] = s_hist[t];
+    if (threadIdx.x == 0) row[ntiles] = (uint32_t)min((unsigned long long)base + total, (unsigned long long)a.bin_cap);
+    __syncthreads(); // rows are read from LDS above before the cursors start moving
+    base_out = base; total_out = total;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1 geometry in ONE pass (slots and order keys: frr_device.h).  Thread = input triangle:
 // renderer.rs:113-148 (VS, reject, classify), then for the common unclipped case :180-218 (centroid +
@@ -177,6 +355,87 @@ __device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevU
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // staging is reused by the wave's next triangle
 }
 
+// The unclipped case of geometry_processing after the vertex shader, for one triangle: renderer.rs:180-218 (centroid +
+// stable angle sort of 3), :220-235 (divide, viewport, snap -- done by the caller: s0..s2), :237-243, and the
+// per-triangle prologue of rasterization (:300-320: orientation swap, top-left flags).  Returns the 64-byte record
+// (q0..q3), the binning record, and where input vertices 0 and 1 ended up (d0, d1: for the varyings).
+struct SetupOut { uint4 q0, q1, q2, q3, pbox; int d0, d1; };
+__device__ __forceinline__ SetupOut setup_unclipped(const float pos[3][4], const ScreenVtx &s0, const ScreenVtx &s1, const ScreenVtx &s2)
+{
+    SetupOut o;
+    // centroid (:180-187), n == 3
+    float cx = 0.0f, cy = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) { cx += pos[v][0]; cy += pos[v][1]; }
+    const float inv_n = 1.0f / 3.0f;
+    cx *= inv_n; cy *= inv_n;
+    // The sort of :205-218 only needs the ORDER of the three angles.  With d_v = vertex - centroid
+    // (the very f32 values atan2 would see), angle(a) < angle(b) in [0, 2pi) is decided by the
+    // half plane (sign of dy) and the sign of cross(a, b) -- exact whenever the true angles are
+    // farther apart, and farther from the 0 / pi axis, than SORT_EPS radians, which dwarfs the
+    // < 1e-6 error of the f32 atan2 + 2pi the reference compares.  Anything closer (or non-finite)
+    // takes the exact atan2f keys.
+    float dx[3], dy[3], d2[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) { dx[v] = pos[v][0] - cx; dy[v] = pos[v][1] - cy; d2[v] = dx[v] * dx[v] + dy[v] * dy[v]; }
+    constexpr float SORT_EPS2 = 1.0e-8f; // (1e-4 rad)^2
+    bool lt10, lt20, lt21, le01;
+    {
+        bool safe = true;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) safe = safe && (dy[v] * dy[v] > SORT_EPS2 * d2[v]) && (d2[v] < 1.0e30f);
+        auto less = [&](int a, int b) { // angle(a) < angle(b)
+            const float cr = dx[a] * dy[b] - dy[a] * dx[b];
+            const bool ha = dy[a] < 0.0f, hb = dy[b] < 0.0f;
+            safe = safe && (ha != hb || cr * cr > SORT_EPS2 * (d2[a] * d2[b]));
+            return ha != hb ? hb : cr > 0.0f;
+        };
+        lt10 = less(1, 0); lt20 = less(2, 0); lt21 = less(2, 1); le01 = !lt10;
+        if (!safe) {
+            int32_t key[3];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) key[v] = total_order_key(sort_angle(dy[v], dx[v]));
+            lt10 = key[1] < key[0]; lt20 = key[2] < key[0]; lt21 = key[2] < key[1]; le01 = key[0] <= key[1];
+        }
+    }
+    // stable rank of each vertex (:205-218)
+    int r0 = (int)lt10 + (int)lt20;
+    int r1 = (int)le01 + (int)lt21;
+    // (the third rank is implied by the other two)
+    // Everything below is a permutation of the three vertices: sorted order, then the orientation
+    // swap of renderer.rs:300-312.  It is written as scalar selects on the destination slot of each
+    // input vertex (struct-valued selects end up as runtime-indexed scratch).
+    auto by_rank = [&](int r, float x0, float x1, float x2) { return r0 == r ? x0 : (r1 == r ? x1 : x2); };
+    const float ax = by_rank(0, s0.ndcx, s1.ndcx, s2.ndcx), ay = by_rank(0, s0.ndcy, s1.ndcy, s2.ndcy);
+    const float bx = by_rank(1, s0.ndcx, s1.ndcx, s2.ndcx), by = by_rank(1, s0.ndcy, s1.ndcy, s2.ndcy);
+    const float cx2 = by_rank(2, s0.ndcx, s1.ndcx, s2.ndcx), cy2 = by_rank(2, s0.ndcy, s1.ndcy, s2.ndcy);
+    const float v01x = bx - ax, v01y = by - ay, v02x = cx2 - ax, v02y = cy2 - ay;
+    const bool swap = (v01x * v02y - v02x * v01y) > 0.0f;                 // :300-309
+    auto slot_of = [&](int r) { return r == 0 ? 0 : ((r == 1) != swap ? 1 : 2); };
+    const int d0 = slot_of(r0), d1 = slot_of(r1);                        // destination slot of input vertex 0, 1 (2: the other)
+    auto in_slot_f = [&](int s, float x0, float x1, float x2) { return d0 == s ? x0 : (d1 == s ? x1 : x2); };
+    auto in_slot_i = [&](int s, int x0, int x1, int x2) { return d0 == s ? x0 : (d1 == s ? x1 : x2); };
+    int px[3], py[3];
+    float sx[3], sy[3], rw[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        px[s] = in_slot_i(s, s0.ix, s1.ix, s2.ix); py[s] = in_slot_i(s, s0.iy, s1.iy, s2.iy);
+        sx[s] = in_slot_f(s, s0.sx, s1.sx, s2.sx); sy[s] = in_slot_f(s, s0.sy, s1.sy, s2.sy);
+        rw[s] = in_slot_f(s, s0.rhw, s1.rhw, s2.rhw);
+    }
+    uint32_t flags = swap ? 1u : 0u;
+    flags |= is_top_left(px[0], py[0], px[1], py[1]) ? 0u : 2u;           // :318-320
+    flags |= is_top_left(px[1], py[1], px[2], py[2]) ? 0u : 4u;
+    flags |= is_top_left(px[2], py[2], px[0], py[0]) ? 0u : 8u;
+    { const uint2 pb = pack_pbox(px[0], py[0], px[1], py[1], px[2], py[2]); o.pbox = make_uint4(pb.x, pb.y, cull_zub(rw[0], rw[1], rw[2]), 0u); }
+    o.q0 = make_uint4((uint32_t)px[0], (uint32_t)py[0], (uint32_t)px[1], (uint32_t)py[1]);
+    o.q1 = make_uint4((uint32_t)px[2], (uint32_t)py[2], f2u(sx[0]), f2u(sy[0]));
+    o.q2 = make_uint4(f2u(sx[1]), f2u(sy[1]), f2u(sx[2]), f2u(sy[2]));
+    o.q3 = make_uint4(f2u(rw[0]), f2u(rw[1]), f2u(rw[2]), flags);
+    o.d0 = d0; o.d1 = d1;
+    return o;
+}
+
 // per-draw bookkeeping, by ONE thread of the draw's geometry kernel.  It runs beside the kernel's other blocks, so it
 // touches nothing they touch: the fan cursor of THIS draw was zeroed by the draw before (every geometry path zeroes
 // the other slot -- the slots alternate per draw), and flags are raised only by later kernels (geom_scan, binning).
@@ -244,75 +503,10 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     }
     if (t < g.ntris && !emit) g.pbox[t] = make_uint4(0u, 0u, 0u, 0u); // nothing at slot t (dropped / clipped / not this rank's)
     if (emit) {
-    // centroid (:180-187), n == 3
-    float cx = 0.0f, cy = 0.0f;
-#pragma unroll
-    for (int v = 0; v < 3; ++v) { cx += pos[v][0]; cy += pos[v][1]; }
-    const float inv_n = 1.0f / 3.0f;
-    cx *= inv_n; cy *= inv_n;
-    // The sort of :205-218 only needs the ORDER of the three angles.  With d_v = vertex - centroid
-    // (the very f32 values atan2 would see), angle(a) < angle(b) in [0, 2pi) is decided by the
-    // half plane (sign of dy) and the sign of cross(a, b) -- exact whenever the true angles are
-    // farther apart, and farther from the 0 / pi axis, than SORT_EPS radians, which dwarfs the
-    // < 1e-6 error of the f32 atan2 + 2pi the reference compares.  Anything closer (or non-finite)
-    // takes the exact atan2f keys.
-    float dx[3], dy[3], d2[3];
-#pragma unroll
-    for (int v = 0; v < 3; ++v) { dx[v] = pos[v][0] - cx; dy[v] = pos[v][1] - cy; d2[v] = dx[v] * dx[v] + dy[v] * dy[v]; }
-    constexpr float SORT_EPS2 = 1.0e-8f; // (1e-4 rad)^2
-    bool lt10, lt20, lt21, le01;
-    {
-        bool safe = true;
-#pragma unroll
-        for (int v = 0; v < 3; ++v) safe = safe && (dy[v] * dy[v] > SORT_EPS2 * d2[v]) && (d2[v] < 1.0e30f);
-        auto less = [&](int a, int b) { // angle(a) < angle(b)
-            const float cr = dx[a] * dy[b] - dy[a] * dx[b];
-            const bool ha = dy[a] < 0.0f, hb = dy[b] < 0.0f;
-            safe = safe && (ha != hb || cr * cr > SORT_EPS2 * (d2[a] * d2[b]));
-            return ha != hb ? hb : cr > 0.0f;
-        };
-        lt10 = less(1, 0); lt20 = less(2, 0); lt21 = less(2, 1); le01 = !lt10;
-        if (!safe) {
-            int32_t key[3];
-#pragma unroll
-            for (int v = 0; v < 3; ++v) key[v] = total_order_key(sort_angle(dy[v], dx[v]));
-            lt10 = key[1] < key[0]; lt20 = key[2] < key[0]; lt21 = key[2] < key[1]; le01 = key[0] <= key[1];
-        }
-    }
-    // stable rank of each vertex (:205-218)
-    int r0 = (int)lt10 + (int)lt20;
-    int r1 = (int)le01 + (int)lt21;
-    // (the third rank is implied by the other two)
-    // Everything below is a permutation of the three vertices: sorted order, then the orientation
-    // swap of renderer.rs:300-312.  It is written as scalar selects on the destination slot of each
-    // input vertex (struct-valued selects end up as runtime-indexed scratch).
-    auto by_rank = [&](int r, float x0, float x1, float x2) { return r0 == r ? x0 : (r1 == r ? x1 : x2); };
-    const float ax = by_rank(0, s0.ndcx, s1.ndcx, s2.ndcx), ay = by_rank(0, s0.ndcy, s1.ndcy, s2.ndcy);
-    const float bx = by_rank(1, s0.ndcx, s1.ndcx, s2.ndcx), by = by_rank(1, s0.ndcy, s1.ndcy, s2.ndcy);
-    const float cx2 = by_rank(2, s0.ndcx, s1.ndcx, s2.ndcx), cy2 = by_rank(2, s0.ndcy, s1.ndcy, s2.ndcy);
-    const float v01x = bx - ax, v01y = by - ay, v02x = cx2 - ax, v02y = cy2 - ay;
-    const bool swap = (v01x * v02y - v02x * v01y) > 0.0f;                 // :300-309
-    auto slot_of = [&](int r) { return r == 0 ? 0 : ((r == 1) != swap ? 1 : 2); };
-    const int d0 = slot_of(r0), d1 = slot_of(r1);                        // destination slot of input vertex 0, 1 (2: the other)
-    auto in_slot_f = [&](int s, float x0, float x1, float x2) { return d0 == s ? x0 : (d1 == s ? x1 : x2); };
-    auto in_slot_i = [&](int s, int x0, int x1, int x2) { return d0 == s ? x0 : (d1 == s ? x1 : x2); };
-    int px[3], py[3];
-    float sx[3], sy[3], rw[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        px[s] = in_slot_i(s, s0.ix, s1.ix, s2.ix); py[s] = in_slot_i(s, s0.iy, s1.iy, s2.iy);
-        sx[s] = in_slot_f(s, s0.sx, s1.sx, s2.sx); sy[s] = in_slot_f(s, s0.sy, s1.sy, s2.sy);
-        rw[s] = in_slot_f(s, s0.rhw, s1.rhw, s2.rhw);
-    }
-    uint32_t flags = swap ? 1u : 0u;
-    flags |= is_top_left(px[0], py[0], px[1], py[1]) ? 0u : 2u;           // :318-320
-    flags |= is_top_left(px[1], py[1], px[2], py[2]) ? 0u : 4u;
-    flags |= is_top_left(px[2], py[2], px[0], py[0]) ? 0u : 8u;
-    { const uint2 pb = pack_pbox(px[0], py[0], px[1], py[1], px[2], py[2]); g.pbox[t] = make_uint4(pb.x, pb.y, cull_zub(rw[0], rw[1], rw[2]), 0u); }
-    const uint4 q0 = make_uint4((uint32_t)px[0], (uint32_t)py[0], (uint32_t)px[1], (uint32_t)py[1]);
-    const uint4 q1 = make_uint4((uint32_t)px[2], (uint32_t)py[2], f2u(sx[0]), f2u(sy[0]));
-    const uint4 q2 = make_uint4(f2u(sx[1]), f2u(sy[1]), f2u(sx[2]), f2u(sy[2]));
-    const uint4 q3 = make_uint4(f2u(rw[0]), f2u(rw[1]), f2u(rw[2]), flags);
+    const SetupOut so = setup_unclipped(pos, s0, s1, s2);
+    g.pbox[t] = so.pbox;
+    const uint4 q0 = so.q0, q1 = so.q1, q2 = so.q2, q3 = so.q3;
+    auto in_slot_f = [&](int sl, float x0, float x1, float x2) { return so.d0 == sl ? x0 : (so.d1 == sl ? x1 : x2); };
     {
         // The lanes that are here write the record of their own slot t; when they are a run of consecutive lanes (the
         // usual case: every lane) the records are consecutive in memory.  A lane-per-record store writes 16 B at a 64-B
@@ -406,22 +600,6 @@ __global__ __launch_bounds__(1024) void k_geom_scan(uint32_t *sums, uint32_t nbl
 // ---------------------------------------------------------------------------------------------
 constexpr int BIN_COOP = 6;
 
-struct TileRange { int tx0, tx1, ty0, ty1; }; // inclusive-exclusive tile ranges (window-local)
-
-
-__device__ __forceinline__ TileRange tiles_of_pbox(const RasterArgs &a, const uint4 b)
-{
-    const int mnx = (int)(short)(b.x & 0xFFFFu), mny = (int)(short)(b.x >> 16);
-    const int mxx = (int)(short)(b.y & 0xFFFFu), mxy = (int)(short)(b.y >> 16);
-    const int minx = clampi(mnx, a.x0, a.x1), maxx = clampi(mxx, a.x0, a.x1);
-    const int miny = clampi(mny, a.y0, a.y1), maxy = clampi(mxy, a.y0, a.y1);
-    TileRange t;
-    if (maxx <= minx || maxy <= miny) { t.tx0 = t.tx1 = t.ty0 = t.ty1 = 0; return t; }
-    t.tx0 = (minx - a.x0) / TILE; t.tx1 = (maxx - 1 - a.x0) / TILE + 1;
-    t.ty0 = (miny - a.y0) / TILE; t.ty1 = (maxy - 1 - a.y0) / TILE + 1;
-    return t;
-}
-
 // slots of the current draw to walk: the inputs' own slots and the fan slots handed out (frr_device.h)
 __device__ __forceinline__ uint32_t draw_slots(const Counters *cnt, int fslot, uint32_t fan_cap)
 {
@@ -513,9 +691,6 @@ __global__ __launch_bounds__(1024) void k_tile_scan(RasterArgs a, uint32_t ntile
 // scan, no CSR scan and no second launch are needed.  The global-atomic CSR path (k_bin above) remains
 // as the fallback when the tile count does not fit LDS.
 // ---------------------------------------------------------------------------------------------
-constexpr int BIN_WG = 1024;
-constexpr int BIN_MAX_G = 256;
-constexpr uint32_t BIN_LDS_MAX_TILES = 36864; // 144 KiB of u32 counters
 
 __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg, int slot,
                                                     uint32_t stage_cap, int fslot, uint32_t fan_cap, uint32_t *block_sums, uint32_t nblocks, int do_scan)
@@ -524,9 +699,6 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     // needs the prefix for triangle ids; here it costs no launch and sits on nobody's critical path)
     if (do_scan && blockIdx.x == gridDim.x - 1) { geom_scan(block_sums, nblocks, a.cnt, fslot, fan_cap); return; }
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[]; // [ntiles], then the staging records
-    // the first stage_cap records of the workgroup's region are collected in LDS in their final order and
-    // leave as coalesced full-line stores (a scattered 16-B store is a partial-line write: WRITE_SIZE showed
-    // 2.3x the bytes); what does not fit goes straight to memory
     uint4 *s_stage = reinterpret_cast<uint4 *>(s_hist + ((ntiles + 3u) & ~3u));
     __shared__ uint32_t s_w[BIN_WG / 64];
     __shared__ uint32_t s_base;
@@ -544,138 +716,13 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     const uint32_t lo = min(n, g * chunk), hi = min(n, lo + chunk);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int PF = 4; // bboxes of PF rounds are fetched up front: the loop is latency-bound otherwise
-    uint32_t region = 0; // first record of this workgroup's region (known before the scatter walk)
-    auto put = [&](uint32_t pos, const uint4 &ent) { // pos = ~0u: nothing
-        const uint32_t local = pos - region;
-        if (pos != ~0u) {
-            if (local < stage_cap) s_stage[local] = ent;
-            else if (pos < a.bin_cap) a.bins[pos] = ent;
-        }
-    };
-    auto walk = [&](auto scatter_tag) {
-        constexpr bool SCATTER = decltype(scatter_tag)::value;
-        for (uint32_t base0 = lo + wave * 64u; base0 < hi; base0 += PF * BIN_WG) {
-            uint4 pb[PF];
-#pragma unroll
-            for (int k = 0; k < PF; ++k) {
-                const uint32_t i = base0 + k * BIN_WG + lane;
-                pb[k] = i < hi ? a.pbox[i] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
-            }
-#pragma unroll
-            for (int k = 0; k < PF; ++k) {
-                const uint32_t base = base0 + k * BIN_WG;
-                if (base >= hi) break;
-                const uint32_t i = base + lane;
-                const TileRange t = tiles_of_pbox(a, pb[k]);
-                const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
-                const int nt = ntx * nty;
-                auto visit = [&](const uint4 &ent, int tx, int ty) {
-                    if (!owns_tile_row(ty, a.rank, a.world, a.rpr)) return;
-                    const int tile = local_tile_row(ty, a.rank, a.world, a.rpr) * a.tiles_x + tx;
-                    if constexpr (SCATTER) {
-                        put(atomicAdd(&s_hist[tile], 1u), ent);
-                    } else {
-                        atomicAdd(&s_hist[tile], 1u);
-                    }
-                };
-                const uint4 mine = make_uint4(i, pb[k].z, pb[k].x, pb[k].y);
-                // footprints of at most 2x2 tiles (the common case) as straight-line code: up to four
-                // independent LDS atomics in flight instead of a loop of dependent atomic -> store steps
-                const bool small = nt > 0 && ntx <= 2 && nty <= 2;
-                if (small) {
-                    const bool own0 = owns_tile_row(t.ty0, a.rank, a.world, a.rpr);
-                    const bool own1 = nty == 2 && owns_tile_row(t.ty0 + 1, a.rank, a.world, a.rpr);
-                    const int t00 = local_tile_row(t.ty0, a.rank, a.world, a.rpr) * a.tiles_x + t.tx0;
-                    const int t10 = local_tile_row(t.ty0 + 1, a.rank, a.world, a.rpr) * a.tiles_x + t.tx0;
-                    const bool v0 = own0, v1 = own0 && ntx == 2, v2 = own1, v3 = own1 && ntx == 2;
-                    if constexpr (SCATTER) {
-                        uint32_t p0 = ~0u, p1 = ~0u, p2 = ~0u, p3 = ~0u;
-                        if (v0) p0 = atomicAdd(&s_hist[t00], 1u);
-                        if (v1) p1 = atomicAdd(&s_hist[t00 + 1], 1u);
-                        if (v2) p2 = atomicAdd(&s_hist[t10], 1u);
-                        if (v3) p3 = atomicAdd(&s_hist[t10 + 1], 1u);
-                        put(p0, mine); put(p1, mine); put(p2, mine); put(p3, mine);
-                    } else {
-                        if (v0) atomicAdd(&s_hist[t00], 1u);
-                        if (v1) atomicAdd(&s_hist[t00 + 1], 1u);
-                        if (v2) atomicAdd(&s_hist[t10], 1u);
-                        if (v3) atomicAdd(&s_hist[t10 + 1], 1u);
-                    }
-                }
-                // footprints up to 3x3 tiles, same idea (nine predicated positions); skipped by waves without any
-                const bool mid = nt > 0 && !small && ntx <= 3 && nty <= 3;
-                if (__ballot(mid)) {
-                    uint32_t pos[9];
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const bool own = mid && dy < nty && owns_tile_row(t.ty0 + dy, a.rank, a.world, a.rpr);
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            const bool v = own && dx < ntx;
-                            const int tile = local_tile_row(t.ty0 + dy, a.rank, a.world, a.rpr) * a.tiles_x + t.tx0 + dx;
-                            pos[dy * 3 + dx] = ~0u;
-                            if constexpr (SCATTER) { if (v) pos[dy * 3 + dx] = atomicAdd(&s_hist[tile], 1u); }
-                            else { if (v) atomicAdd(&s_hist[tile], 1u); }
-                        }
-                    }
-                    if constexpr (SCATTER) {
-#pragma unroll
-                        for (int q = 0; q < 9; ++q) put(pos[q], mine);
-                    }
-                }
-                // larger footprints: four at a time, each spread over a quarter of the wave (16 lanes)
-                unsigned long long big = __ballot(nt > 0 && !small && !mid);
-                while (big) {
-                    int src = -1;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int sj = big ? __builtin_ctzll(big) : -1;
-                        big &= big - 1;                    // (0 stays 0)
-                        if ((lane >> 4) == j) src = sj;
-                    }
-                    const int sl = src < 0 ? 0 : src;
-                    const int bx0 = __shfl(t.tx0, sl), by0 = __shfl(t.ty0, sl), bnx = __shfl(ntx, sl);
-                    const int bnt_src = __shfl(nt, sl); // unconditional: a cross-lane read must not sit under `src >= 0` (inactive source lanes read as 0)
-                    const int bnt = src < 0 ? 0 : bnt_src;
-                    const uint4 ent = make_uint4(base + sl, __shfl(pb[k].z, sl), __shfl(pb[k].x, sl), __shfl(pb[k].y, sl));
-                    for (int q = lane & 15; q < bnt; q += 16) visit(ent, bx0 + q % bnx, by0 + q / bnx);
-                }
-            }
-        }
-    };
-    walk(std::false_type{});
+    BinPut put{s_stage, a.bins, 0u, stage_cap, a.bin_cap};
+    bin_walk<false>(a, s_hist, a.pbox, lo, hi, lane, wave, put);
     __syncthreads();
-    // exclusive scan over tiles, in place: thread i owns the slice [i*per, (i+1)*per)
-    const uint32_t per = (ntiles + BIN_WG - 1) / BIN_WG;
-    const uint32_t t0 = min(ntiles, threadIdx.x * per), t1 = min(ntiles, t0 + per);
-    uint32_t sum = 0;
-    for (uint32_t t = t0; t < t1; ++t) sum += s_hist[t];
-    const uint32_t inc = wave_incl_scan(sum);
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < BIN_WG / 64; ++k) { const uint32_t x = s_w[k]; if (k < (int)wave) wbase += x; total += x; }
-    if (threadIdx.x == 0) {
-        const unsigned long long b64 = atomicAdd(&a.cnt->seg_total[slot], (unsigned long long)total);
-        uint32_t base = (uint32_t)b64;
-        if (b64 + total > (unsigned long long)a.bin_cap) { atomicOr(&a.cnt->overflow, 2u); base = a.bin_cap; } // frame flagged invalid; nothing of this chunk is stored
-        s_base = base;
-    }
-    __syncthreads();
-    const uint32_t base = s_base;
-    uint32_t *__restrict__ row = seg + (size_t)g * (ntiles + 1);
-    {
-        uint32_t run = base + (wbase + inc - sum);
-        for (uint32_t t = t0; t < t1; ++t) { const uint32_t x = s_hist[t]; s_hist[t] = min(run, a.bin_cap); run += x; }
-    }
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) row[t] = s_hist[t];
-    if (threadIdx.x == 0) row[ntiles] = (uint32_t)min((unsigned long long)base + total, (unsigned long long)a.bin_cap);
-    __syncthreads(); // rows are read from LDS above before the cursors start moving
-    region = base;
-    walk(std::true_type{});
+    uint32_t base, total;
+    bin_reserve_publish(a, s_hist, ntiles, seg + (size_t)g * (ntiles + 1), slot, s_w, &s_base, lane, wave, base, total);
+    put.region = base;
+    bin_walk<true>(a, s_hist, a.pbox, lo, hi, lane, wave, put);
     __syncthreads();
     const uint32_t nstaged = min(total, stage_cap);
     for (uint32_t j = threadIdx.x; j < nstaged; j += BIN_WG)
