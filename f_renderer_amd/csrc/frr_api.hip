@@ -14,9 +14,9 @@ using namespace frr;
 
 namespace {
 
-enum KernelId { KID_CLEAR, KID_GEOM, KID_GEOM_SCAN, KID_GEOM_UNUSED, KID_BIN_COUNT,
+enum KernelId { KID_CLEAR, KID_GEOM, KID_GEOM_SCAN, KID_GEOM_BIN, KID_BIN_COUNT,
                 KID_TILE_SCAN, KID_BIN_FILL, KID_RASTER, KID_BIN_SEG, KID_COUNT };
-const char *const kKernelNames[KID_COUNT] = {"k_clear", "k_geom", "k_geom_scan", "k_unused",
+const char *const kKernelNames[KID_COUNT] = {"k_clear", "k_geom", "k_geom_scan", "k_geom_bin",
                                              "k_bin_count", "k_tile_scan", "k_bin_fill",
                                              "k_raster", "k_bin_seg"};
 
@@ -54,6 +54,11 @@ struct frr_ctx {
     uint32_t geom_fan_cap = 0; // fan capacity the latest draw was launched with
     uint32_t geom_nblocks = 0;
     bool scan_pending = false; // the latest draw's block sums are not scanned yet (geom_scan: by the binning launch, or k_geom_scan)
+    bool geom_deferred = false; // frr_draw: the geometry kernel is not launched yet (frr_raster may fuse it with the binning)
+    GeomArgs geom_args;         //   ... its arguments
+    bool no_fuse = true;        // FRR_FUSE=1 fuses frr_draw's geometry and binning into one launch (k_geom_bin): parity-tested, but measured
+                                // 4-7 % slower per frame than the two launches (1024-thread workgroups halve the geometry phase's occupancy)
+    bool fuse_attr_set[4] = {false, false, false, false};
     size_t fan_hint = 0;       // fan capacity asked for by a draw that overflowed
     int bin_g = 0;             // FRR_BIN_G: override the number of binning chunks (dev)
     uint32_t ent_slot_override = 0; // FRR_ENT_SLOT: per-tile slot of bins2 in records (tests of the overflow arena)
@@ -217,9 +222,28 @@ template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks
     hipLaunchKernelGGL(k_geom_single<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni);
 }
 
+// the geometry kernel proper (unfused), for the VS of the mesh
+void launch_geometry_vs(frr_ctx *c, GeomArgs &g, uint32_t nblocks, int vs)
+{
+    switch (vs) {
+    case FRR_VS_CLIP: launch_geometry<FRR_VS_CLIP>(c, g, nblocks); break;
+    case FRR_VS_CLIP_COLOR: launch_geometry<FRR_VS_CLIP_COLOR>(c, g, nblocks); break;
+    case FRR_VS_PHONG: launch_geometry<FRR_VS_PHONG>(c, g, nblocks); break;
+    case FRR_VS_GOURAUD: launch_geometry<FRR_VS_GOURAUD>(c, g, nblocks); break;
+    }
+}
+// frr_draw defers its geometry launch so that frr_raster can fuse it with the binning; whoever cannot fuse launches it here
+void flush_deferred_geometry(frr_ctx *c)
+{
+    if (!c->geom_deferred) return;
+    c->geom_deferred = false;
+    launch_geometry_vs(c, c->geom_args, c->geom_nblocks, c->geom_vs);
+}
+
 // the latest draw's block sums -> prefix (+ n_emit, the fan-capacity flag), if no binning launch has done it
 int scan_now(frr_ctx *c)
 {
+    flush_deferred_geometry(c);
     if (!c->scan_pending) return FRR_OK;
     { ProfScope p(c, KID_GEOM_SCAN); hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, c->stream, c->block_sums, c->geom_nblocks, c->cnt, c->geom_slot, c->geom_fan_cap); }
     HIP_TRY(c, hipGetLastError());
@@ -236,13 +260,13 @@ int scan_now(frr_ctx *c)
 struct SpanShape { int nw, occ; };
 SpanShape span_shape(const frr_ctx *c, uint32_t grid, uint64_t ntris, int ps_id)
 {
-    static const SpanShape all[] = {{16, 4}, {8, 6}, {6, 6}, {4, 8}, {4, 6}, {3, 6}};
+    static const SpanShape all[] = {{16, 4}, {8, 6}, {6, 6}, {4, 8}, {4, 6}, {LIGHT_NW, 6}};
     if (c->raster_nw || c->raster_occ)                   // FRR_RASTER_NW / FRR_RASTER_OCC (tests, tools)
         for (const SpanShape &k : all)
             if ((!c->raster_nw || k.nw == c->raster_nw) && (!c->raster_occ || k.occ == c->raster_occ)) return k;
     if (grid <= 256u) return {16, 4};
     if (grid <= 768u) return {8, 6};
-    if (ps_id == FRR_PS_DEPTH && grid > 1536u && ntris * 2u <= 192ull * grid) return {3, 6};
+    if (ps_id == FRR_PS_DEPTH && grid > 1536u && ntris * 2u <= 192ull * grid) return {LIGHT_NW, 6};
     return {4, 6};
 }
 
@@ -260,7 +284,7 @@ template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uin
             hipLaunchKernelGGL((k_raster_span<K, PS, CNT, NWV, OCCV>), dim3(grid), dim3(NWV * 64), 0, c->stream, a, c->duni, win_safe);
         };
         auto go_nw = [&](auto count_tag) {
-            if (sh.nw == 3) go(count_tag, std::integral_constant<int, 3>{}, std::integral_constant<int, 6>{});
+            if (sh.nw == LIGHT_NW) go(count_tag, std::integral_constant<int, LIGHT_NW>{}, std::integral_constant<int, 6>{});
             else if (sh.nw == 4 && sh.occ == 8) go(count_tag, std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
             else if (sh.nw == 4) go(count_tag, std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
             else if (sh.nw == 6) go(count_tag, std::integral_constant<int, 6>{}, std::integral_constant<int, 6>{});
@@ -317,6 +341,7 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     { const char *e = getenv("FRR_RASTER_NW"); const int v = e ? atoi(e) : 0; c->raster_nw = (v == 3 || v == 4 || v == 6 || v == 8 || v == 16) ? v : 0; }
     { const char *e = getenv("FRR_RASTER_OCC"); const int v = e ? atoi(e) : 0; c->raster_occ = (v == 4 || v == 6 || v == 8) ? v : 0; }
     { const char *e = getenv("FRR_BIN_G"); c->bin_g = e ? atoi(e) : 0; }
+    { const char *e = getenv("FRR_FUSE"); c->no_fuse = !(e && strcmp(e, "1") == 0); }
     { const char *e = getenv("FRR_CLEAR"); c->clear_eager = e && strcmp(e, "eager") == 0; }
     { const char *e = getenv("FRR_ENT_SLOT"); c->ent_slot_override = e ? (uint32_t)atoi(e) : 0u; }
     { const char *e = getenv("FRR_BIN"); c->bin_atomics = e && strcmp(e, "atomics") == 0; }
@@ -563,7 +588,7 @@ int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
     return FRR_OK;
 }
 
-static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filter, int32_t fy0, int32_t fy1)
+static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filter, int32_t fy0, int32_t fy1, bool defer = false)
 {
     if (!c || mesh < 0 || mesh >= (int)c->meshes.size() || !c->meshes[mesh].used) return fail(c, FRR_ERR_INVALID, "bad mesh id");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -610,19 +635,18 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     c->geom_fan_cap = (uint32_t)fan_cap;
     c->geom_nblocks = nblocks;
     c->counters_pending = false;
+    c->geom_vs = m.vs; c->geom_ntris = nt;
     if (nt == 0) {
         hipLaunchKernelGGL(k_geom_empty, dim3(1), dim3(64), 0, c->stream, g);
+    } else if (defer) {
+        c->geom_args = g;          // frr_draw: frr_raster launches it, fused with the binning when it can
+        c->geom_deferred = true;
+        c->scan_pending = true;
     } else {
-        switch (m.vs) {
-        case FRR_VS_CLIP: launch_geometry<FRR_VS_CLIP>(c, g, nblocks); break;
-        case FRR_VS_CLIP_COLOR: launch_geometry<FRR_VS_CLIP_COLOR>(c, g, nblocks); break;
-        case FRR_VS_PHONG: launch_geometry<FRR_VS_PHONG>(c, g, nblocks); break;
-        case FRR_VS_GOURAUD: launch_geometry<FRR_VS_GOURAUD>(c, g, nblocks); break;
-        }
+        launch_geometry_vs(c, g, nblocks, m.vs);
         c->scan_pending = true;
     }
     HIP_TRY(c, hipGetLastError());
-    c->geom_vs = m.vs; c->geom_ntris = nt;
     if (ntris_setup) {
         if ((rc = scan_now(c)) != FRR_OK) return rc;
         Counters h;
@@ -703,10 +727,10 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         // (small meshes: one triangle per thread, so that the launch is not three workgroups doing all the work)
         uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + BIN_WG - 1) / BIN_WG, 1), BIN_MAX_G);
         if (c->bin_g > 0) G = (uint32_t)std::min(c->bin_g, BIN_MAX_G);
-        G = std::min<uint32_t>(G, (uint32_t)sh.nw * 64u); // the tile kernel reads one segment per thread
+        G = std::min<uint32_t>(G, sh.nw == 3 ? 256u : (uint32_t)sh.nw * 64u); // the tile kernel reads one segment per thread (three waves: wave 0 reads a second one)
         // (+ one workgroup that scans the geometry kernel's block sums, unless an earlier launch has; a binning workgroup
         // fills a CU's LDS, so the launch stays within 256 workgroups: a 257th would wait for a whole one to finish)
-        const int do_scan = c->scan_pending ? 1 : 0;
+        int do_scan = c->scan_pending ? 1 : 0;
         if (do_scan && G > 255u) G = 255u;
         if ((rc = ensure(c, c->bin_matrix, c->bin_matrix_cap, (size_t)BIN_MAX_G * ((size_t)c->max_tiles + 1))) != FRR_OK) return rc;
         // dynamic LDS: tile counters + as many staged 16-B records as fit (a chunk emits ~1.8 records per triangle)
@@ -718,6 +742,20 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
             HIP_TRY(c, hipFuncSetAttribute((const void *)k_bin_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
             c->lds_attr_set = true;
         }
+        // frr_draw's geometry is still to be launched: fuse it with the binning when the geometry phase's staging fits
+        // beside the tile histogram and a workgroup's chunk is at most GB_MAX_ROUNDS rounds
+        uint32_t fchunk = 0;
+        bool fuse = false;
+        if (c->geom_deferred && !c->no_fuse) {
+            const uint32_t gmax = std::min<uint32_t>((uint32_t)BIN_MAX_G, sh.nw == 3 ? 256u : (uint32_t)sh.nw * 64u);
+            fchunk = (uint32_t)(((c->geom_ntris + gmax - 1) / gmax + BIN_WG - 1) / BIN_WG * BIN_WG);
+            const size_t geom_lds = c->geom_vs == FRR_VS_CLIP ? (size_t)GeomBinLds<FRR_VS_CLIP>::END :
+                                    c->geom_vs == FRR_VS_CLIP_COLOR ? (size_t)GeomBinLds<FRR_VS_CLIP_COLOR>::END :
+                                    c->geom_vs == FRR_VS_PHONG ? (size_t)GeomBinLds<FRR_VS_PHONG>::END : (size_t)GeomBinLds<FRR_VS_GOURAUD>::END;
+            fuse = fchunk <= (uint32_t)GB_MAX_ROUNDS * BIN_WG && hist_bytes + geom_lds <= kLdsBudget;
+        }
+        if (fuse) G = (uint32_t)((c->geom_ntris + fchunk - 1) / fchunk);
+        else flush_deferred_geometry(c);
         c->bin_slot ^= 1;
         a.seg = c->bin_matrix; a.nseg = G; a.slot = c->bin_slot;
         // near-first copies (bins2): a fixed slot per tile, 8x the mean tile load, + an overflow arena of bin_cap records
@@ -728,12 +766,36 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xBFFFFFFFu);
         if ((rc = ensure(c, c->bins2, c->bin2_cap, (size_t)ltiles * S + a.bin_cap)) != FRR_OK) return rc;
         a.bins2 = c->bins2;
-        { ProfScope p(c, KID_BIN_SEG); hipLaunchKernelGGL(k_bin_seg, dim3(G + do_scan), dim3(BIN_WG), lds, c->stream, a, ltiles, c->bin_matrix, a.slot, stage_cap,
-                                                          c->geom_slot, c->geom_fan_cap, c->block_sums, c->geom_nblocks, do_scan); }
+        if (fuse) {
+            // geometry + binning in one launch; its last workgroup scans the block sums
+            ProfScope p(c, KID_GEOM_BIN);
+            c->geom_deferred = false;
+            GeomArgs &g = c->geom_args;
+            auto go = [&](auto vs_tag) {
+                constexpr int VSV = decltype(vs_tag)::value;
+                const size_t flds = hist_bytes + std::max<size_t>((size_t)GeomBinLds<VSV>::END, (size_t)stage_cap * 16);
+                if (!c->fuse_attr_set[VSV]) {
+                    (void)hipFuncSetAttribute((const void *)k_geom_bin<VSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+                    c->fuse_attr_set[VSV] = true;
+                }
+                hipLaunchKernelGGL(k_geom_bin<VSV>, dim3(G), dim3(BIN_WG), flds, c->stream, g, c->duni, a, ltiles, c->bin_matrix, a.slot, stage_cap,
+                                   c->geom_nblocks, fchunk);
+            };
+            switch (c->geom_vs) {
+            case FRR_VS_CLIP: go(std::integral_constant<int, FRR_VS_CLIP>{}); break;
+            case FRR_VS_CLIP_COLOR: go(std::integral_constant<int, FRR_VS_CLIP_COLOR>{}); break;
+            case FRR_VS_PHONG: go(std::integral_constant<int, FRR_VS_PHONG>{}); break;
+            default: go(std::integral_constant<int, FRR_VS_GOURAUD>{}); break;
+            }
+        } else {
+            ProfScope p(c, KID_BIN_SEG);
+            hipLaunchKernelGGL(k_bin_seg, dim3(G + do_scan), dim3(BIN_WG), lds, c->stream, a, ltiles, c->bin_matrix, a.slot, stage_cap,
+                               c->geom_slot, c->geom_fan_cap, c->block_sums, c->geom_nblocks, do_scan);
+        }
         c->scan_pending = false;
     } else {
         // fallback for frames with more tiles than fit LDS counters: global atomics
-        if ((rc = scan_now(c)) != FRR_OK) return rc;
+        if ((rc = scan_now(c)) != FRR_OK) return rc;   // (also launches a deferred geometry kernel)
         const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((c->geom_ntris + c->geom_fan_cap + 255) / 256, 2048);
         { ProfScope p(c, KID_BIN_COUNT); hipLaunchKernelGGL(k_bin<false>, dim3(bin_grid), dim3(256), 0, c->stream, a, c->geom_slot, c->geom_fan_cap); }
         { ProfScope p(c, KID_TILE_SCAN); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, a, ntiles); }
@@ -764,9 +826,11 @@ int frr_draw(frr_ctx *c, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0
     // frr_draw knows the raster window, so a partitioned ctx can skip the setup records of triangles
     // that touch none of its tile rows (frr_geometry alone cannot: the window comes later)
     const bool filter = c && c->world > 1 && y0 <= y1;
-    int rc = geometry_impl(c, mesh, nullptr, filter, y0, y1);
+    int rc = geometry_impl(c, mesh, nullptr, filter, y0, y1, /*defer=*/true);
     if (rc != FRR_OK) return rc;
-    return frr_raster(c, ps_id, x0, x1, y0, y1);
+    rc = frr_raster(c, ps_id, x0, x1, y0, y1);
+    flush_deferred_geometry(c);   // (an frr_raster that returned early or failed has not launched it)
+    return rc;
 }
 
 int frr_sync(frr_ctx *c)

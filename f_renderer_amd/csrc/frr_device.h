@@ -42,7 +42,8 @@ struct Counters {
     uint64_t bin_entries_frame;
     uint32_t draws;
     uint32_t need_fans;     // fan slots the current draw needs (valid even on overflow)
-    uint32_t pad0, pad1;
+    uint32_t done_ctr;      // fused geometry + binning launch: workgroups that have finished (the last one scans the block sums)
+    uint32_t skip_prev_bins; // set by the frame reset: the other binning slot holds the PREVIOUS frame's count, not to be added
     unsigned long long seg_total[2]; // segmented binning: entries reserved by the current / previous draw (slots alternate per draw)
     uint32_t fan_cursor[2];          // fan slots handed out by the current / previous draw's geometry kernel (slots alternate)
     uint32_t ent_cursor[2];          // tile kernel: space handed out in the overflow arena of bins2 (same slots)
@@ -157,11 +158,21 @@ __device__ __forceinline__ int local_tile_row(int ty, int rank, int world, int r
 __device__ __forceinline__ void reset_frame_counters(Counters *cnt)
 {
     cnt->n_emit = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
-    cnt->seg_total[0] = cnt->seg_total[1] = 0ull; cnt->ent_cursor[0] = cnt->ent_cursor[1] = 0u;
-    // (NOT the fan cursors: the bookkeeping thread that calls this runs beside geometry blocks that are already
-    // allocating from the current draw's cursor; every geometry kernel zeroes the OTHER slot for the next draw)
     cnt->frag_covered = 0; cnt->frag_nan = 0; cnt->tris_in = 0; cnt->bin_entries_frame = 0; cnt->draws = 0;
+    cnt->skip_prev_bins = 1u;
+    // NOT the per-draw cursors (fan_cursor, seg_total, ent_cursor): the thread that calls this may run beside
+    // workgroups that are already allocating from the CURRENT draw's slot; the slots alternate per draw and every
+    // draw's kernels zero the OTHER slot for the draw after them
     for (int j = 0; j < DBG_COPIES; ++j) for (int k = 0; k < 24; ++k) cnt->dbg[j][k] = 0;
+}
+
+// the binning launch's bookkeeping (one thread): the other slot belongs to the previous draw, which has drained
+__device__ __forceinline__ void bin_bookkeeping(Counters *cnt, int slot)
+{
+    if (!cnt->skip_prev_bins) cnt->bin_entries_frame += cnt->seg_total[slot ^ 1];
+    cnt->skip_prev_bins = 0u;
+    cnt->seg_total[slot ^ 1] = 0ull;
+    cnt->ent_cursor[slot ^ 1] = 0u;
 }
 
 // ---- glam pieces used by the shader table -------------------------------------

@@ -264,8 +264,9 @@ __device__ __forceinline__ void bin_reserve_publish(const RasterArgs &a, uint32_
 // so "list order" is simply lane order among the kept lanes.
 constexpr int CLIP_MAXV = 21;
 
+// Returns the lane's binning record (all zero for lanes that emit no fan triangle).
 template <int VS>
-__device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevUniforms &u, uint32_t t, uint32_t fbase, int lane,
+__device__ __forceinline__ uint4 clip_triangle_wave(const GeomArgs &g, const DevUniforms &u, uint32_t t, uint32_t fbase, int lane,
                                                    float (*s_xy)[2], int32_t *s_key, float (*s_v)[7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)])
 {
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K, KS = K > 0 ? K : 1;
@@ -323,6 +324,7 @@ __device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevU
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // fan (:237-266): n == 3 -> [0,1,2]; else [0,last-1,last] for last = n-1 .. 4, then [0,2,3], [0,1,2]
+    uint4 mine = make_uint4(0u, 0u, 0u, 0u);
     if (lane < n - 2) {
         const int q = lane;
         int i1, i2;
@@ -340,7 +342,7 @@ __device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevU
         const uint32_t fslot = fbase + (uint32_t)q;             // fan triangle q of input t: emission order is q order
         const uint32_t idx = g.ntris + fslot;
         g.fan_okey[fslot] = (t << FAN_BITS) + 1u + (uint32_t)q;
-        { const uint2 pb = pack_pbox(p0x, p0y, p1x, p1y, p2x, p2y); g.pbox[idx] = make_uint4(pb.x, pb.y, cull_zub(v0[0], v1[0], v2[0]), 0u); }
+        { const uint2 pb = pack_pbox(p0x, p0y, p1x, p1y, p2x, p2y); mine = make_uint4(pb.x, pb.y, cull_zub(v0[0], v1[0], v2[0]), 0u); g.pbox[idx] = mine; }
         uint4 *dst = reinterpret_cast<uint4 *>(g.recs + idx);
         dst[0] = make_uint4((uint32_t)p0x, (uint32_t)p0y, (uint32_t)p1x, (uint32_t)p1y);
         dst[1] = make_uint4((uint32_t)p2x, (uint32_t)p2y, f2u(v0[3]), f2u(v0[4]));
@@ -353,6 +355,7 @@ __device__ __forceinline__ void clip_triangle_wave(const GeomArgs &g, const DevU
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // staging is reused by the wave's next triangle
+    return mine;
 }
 
 // The unclipped case of geometry_processing after the vertex shader, for one triangle: renderer.rs:180-218 (centroid +
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         for (uint32_t e = (uint32_t)w; e < ncl; e += GEOM_BLOCK / 64) {
             const uint32_t en = s_cl[e];
-            clip_triangle_wave<VS>(g, u, bid * GEOM_BLOCK + (en & 255u), fbase + (en >> 8), lane, s_cxy[w], s_ckey[w], s_cv[w]);
+            (void)clip_triangle_wave<VS>(g, u, bid * GEOM_BLOCK + (en & 255u), fbase + (en >> 8), lane, s_cxy[w], s_ckey[w], s_cv[w]);
         }
     }
 }
@@ -559,7 +562,8 @@ __global__ void k_geom_empty(GeomArgs g)
 // Exclusive scan of the draw's block sums (in place: they become Counters::block_prefix), by one workgroup of 1024
 // threads (the extra workgroup of k_bin_seg, or k_geom_scan on its own); publishes n_emit and raises the capacity flag
 // when the draw asked for more fan slots than there are.
-__device__ __forceinline__ void geom_scan(uint32_t *__restrict__ sums, uint32_t nblocks, Counters *cnt, int fslot, uint32_t fan_cap)
+template <bool AGENT = false>
+__device__ __forceinline__ void geom_scan(uint32_t *sums, uint32_t nblocks, Counters *cnt, int fslot, uint32_t fan_cap)
 {
     __shared__ uint32_t s_sw[16];
     __shared__ uint32_t s_carry;
@@ -568,7 +572,9 @@ __device__ __forceinline__ void geom_scan(uint32_t *__restrict__ sums, uint32_t 
     __syncthreads();
     for (uint32_t base = 0; base < nblocks; base += 1024) {
         uint32_t i = base + threadIdx.x;
-        uint32_t v = i < nblocks ? sums[i] : 0u;
+        // AGENT: the sums were stored by other workgroups of this very launch (write-through stores, counted in by an
+        // agent-scope atomic): read them past this CU's L1
+        uint32_t v = i < nblocks ? (AGENT ? __hip_atomic_load(&sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : sums[i]) : 0u;
         uint32_t inc = wave_incl_scan(v);
         if (lane == 63) s_sw[w] = inc;
         __syncthreads();
@@ -583,7 +589,7 @@ __device__ __forceinline__ void geom_scan(uint32_t *__restrict__ sums, uint32_t 
     }
     if (threadIdx.x == 0) {
         cnt->n_emit = s_carry;
-        const uint32_t fans = cnt->fan_cursor[fslot];
+        const uint32_t fans = __hip_atomic_load(&cnt->fan_cursor[fslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cnt->need_fans = fans;
         if (fans > fan_cap) atomicOr(&cnt->overflow, 1u);
     }
@@ -591,6 +597,182 @@ __device__ __forceinline__ void geom_scan(uint32_t *__restrict__ sums, uint32_t 
 __global__ __launch_bounds__(1024) void k_geom_scan(uint32_t *sums, uint32_t nblocks, Counters *cnt, int fslot, uint32_t fan_cap)
 {
     geom_scan(sums, nblocks, cnt, fslot, fan_cap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1+K2 fused: geometry AND binning of one frr_draw in ONE launch (frr_draw knows the raster window, so the tiles
+// a triangle touches are known the moment it is set up).  Workgroup g of <= 256 (1024 threads, one per CU) owns a chunk
+// of the input triangles and
+//   1. sets them up in rounds of 1024 -- four 256-triangle geometry blocks side by side, the same code and the same
+//      per-block bookkeeping as k_geom_single -- counting every triangle it has just set up (fans included) into its
+//      LDS tile histogram;
+//   2. scans the histogram, reserves its region of `bins` with ONE global atomic and publishes its row of the segment
+//      table (as k_bin_seg);
+//   3. walks its own slots and the fan ranges it handed out again (the 16-byte records are L2-hot: this CU wrote them),
+//      scatters into an LDS staging copy of its region and writes it out coalesced;
+//   4. stores its block sums past L2 (agent scope) and counts itself in: the LAST workgroup to finish scans all block
+//      sums (geom_scan) -- the hand-off is placement independent (MI355X guide, inter-workgroup visibility: write-through
+//      stores, every storing wave's vmcnt(0), workgroup barrier, one agent-scope atomic; the reader learns it is last
+//      from the value its add returned and reads with agent-scope loads).
+// Against k_geom_single + k_bin_seg this saves the 16 MB read-back of the binning records from HBM, a launch boundary
+// and the start-up of a second latency-bound kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int GB_GROUPS = BIN_WG / GEOM_BLOCK; // geometry blocks per round
+constexpr int GB_MAX_ROUNDS = 16;               // rounds per workgroup: chunks up to 16,384 triangles (4.2 M per mesh)
+
+template <int VS> struct GeomBinLds { // the geometry phase's part of the dynamic LDS (the binning phase's staging aliases it)
+    static constexpr int KS = VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1;
+    static constexpr int NWV = BIN_WG / 64;
+    static constexpr int STAGE = 0;                                        // uint4[NWV][256]: 64 records per wave, pieces swizzled
+    static constexpr int CXY = STAGE + NWV * 4096;                         // float[NWV][21][2]
+    static constexpr int CKEY = CXY + NWV * CLIP_MAXV * 8;                 // int32[NWV][21]
+    static constexpr int CV = CKEY + ((NWV * CLIP_MAXV * 4 + 15) & ~15);   // float[NWV][21][7 + KS]
+    static constexpr int CL = CV + ((NWV * CLIP_MAXV * (7 + KS) * 4 + 15) & ~15); // u32[GB_GROUPS][256]
+    static constexpr int END = CL + GB_GROUPS * GEOM_BLOCK * 4;
+};
+
+template <int VS>
+__global__ __launch_bounds__(BIN_WG) void k_geom_bin(GeomArgs g, DevUniforms u, RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg,
+                                                    int bslot, uint32_t stage_cap, uint32_t nblocks, uint32_t chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[]; // [ntiles], then the union {geometry staging | binning staging}
+    using L = GeomBinLds<VS>;
+    constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K, KS = L::KS;
+    unsigned char *const s_u = reinterpret_cast<unsigned char *>(s_hist + ((ntiles + 3u) & ~3u));
+    uint4 *const s_rstage = reinterpret_cast<uint4 *>(s_u + L::STAGE);
+    float (*const s_cxy)[CLIP_MAXV][2] = reinterpret_cast<float (*)[CLIP_MAXV][2]>(s_u + L::CXY);
+    int32_t (*const s_ckey)[CLIP_MAXV] = reinterpret_cast<int32_t (*)[CLIP_MAXV]>(s_u + L::CKEY);
+    float (*const s_cv)[CLIP_MAXV][7 + KS] = reinterpret_cast<float (*)[CLIP_MAXV][7 + KS]>(s_u + L::CV);
+    uint32_t *const s_cl = reinterpret_cast<uint32_t *>(s_u + L::CL);
+    uint4 *const s_bstage = reinterpret_cast<uint4 *>(s_u);
+    __shared__ uint32_t s_w[BIN_WG / 64], s_wf[BIN_WG / 64];
+    __shared__ uint32_t s_ncl[GB_GROUPS], s_fbase[GB_GROUPS];
+    __shared__ uint2 s_fanr[GB_MAX_ROUNDS * GB_GROUPS];   // fan ranges (first slot, count) handed out by this workgroup
+    __shared__ uint32_t s_base, s_last;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = (int)(wave >> 2), wg = (int)(wave & 3u), tin = threadIdx.x & (GEOM_BLOCK - 1);
+    const uint32_t gi = blockIdx.x, G = gridDim.x;
+    for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) s_hist[t] = 0u;
+    if (threadIdx.x < GB_GROUPS) s_ncl[threadIdx.x] = 0u;
+    if (gi == 0 && threadIdx.x == 0) { geom_bookkeeping(g); bin_bookkeeping(g.cnt, bslot); }
+    __syncthreads();
+    const uint32_t lo = min(g.ntris, gi * chunk), hi = min(g.ntris, lo + chunk);
+    const uint32_t rounds = (hi - lo + BIN_WG - 1) / BIN_WG;
+    BinPut put{s_bstage, a.bins, 0u, stage_cap, a.bin_cap};
+    // exclusive scan of one value per thread within each 256-thread group (four waves); total of the group
+    auto group_scan = [&](uint32_t v, uint32_t *sw, uint32_t &total) {
+        const uint32_t inc = wave_incl_scan(v);
+        if (lane == 63) sw[wave] = inc;
+        __syncthreads();
+        const uint32_t w0 = sw[grp * 4], w1 = sw[grp * 4 + 1], w2 = sw[grp * 4 + 2], w3 = sw[grp * 4 + 3];
+        total = w0 + w1 + w2 + w3;
+        return (wg > 0 ? w0 : 0u) + (wg > 1 ? w1 : 0u) + (wg > 2 ? w2 : 0u) + inc - v;
+    };
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t t = lo + r * BIN_WG + threadIdx.x;
+        const uint32_t blk = (lo + r * BIN_WG) / GEOM_BLOCK + (uint32_t)grp;  // this group's geometry block
+        float pos[3][4];
+        float ctx[3][KS];
+        uint32_t n = 0;
+        bool clipped = false;
+        if (t < hi) {
+            const float *in = g.in + (size_t)t * (3 * NF);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
+            n = classify(pos, clipped);
+        }
+        uint32_t total, ftotal;
+        const uint32_t eoff = group_scan(n, s_w, total);
+        const uint32_t foff = group_scan(clipped ? n : 0u, s_wf, ftotal);
+        if (tin == 0) {
+            if (blk < nblocks) __hip_atomic_store(&g.block_sums[blk], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t fb = ftotal ? atomicAdd(&g.cnt->fan_cursor[g.fslot], ftotal) : 0u;
+            s_fbase[grp] = fb;
+            s_fanr[r * GB_GROUPS + grp] = make_uint2(fb, ftotal);
+        }
+        if (t < hi) g.tinfo[t] = n | (eoff << FAN_BITS);
+        __syncthreads();
+        const uint32_t fbase = s_fbase[grp];
+        const bool fans_ok = fbase + ftotal <= g.fan_cap;
+        if (clipped) {
+            g.fanbase[t] = fbase + foff;
+            if (fans_ok) s_cl[grp * GEOM_BLOCK + atomicAdd(&s_ncl[grp], 1u)] = (uint32_t)tin | (foff << 8);
+        }
+        ScreenVtx s0 = {}, s1 = {}, s2 = {};
+        bool emit = false;
+        if (n == 1u && !clipped) {
+            const float fw = (float)g.width, fh = (float)g.height;
+            s0 = to_screen(pos[0], fw, fh); s1 = to_screen(pos[1], fw, fh); s2 = to_screen(pos[2], fw, fh);
+            emit = tri_rows_owned(g, s0.iy, s1.iy, s2.iy);
+        }
+        uint4 my_pbox = make_uint4(0u, 0u, 0u, 0u);
+        if (emit) {
+            const SetupOut so = setup_unclipped(pos, s0, s1, s2);
+            my_pbox = so.pbox;
+            // the 64 records of a wave leave as four coalesced 1-KB stores, staged through LDS: record rk, 16-byte piece j
+            // sits at rk*4 + (j ^ ((rk >> 1) & 3)) -- conflict-free for the b128 writes and the reads alike
+            const unsigned long long am = __ballot(true);
+            const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+            const int np = __popcll(am);
+            const uint32_t t0 = __builtin_amdgcn_readfirstlane(t);
+            if (__ballot(t == t0 + (uint32_t)rk) == am) {
+                uint4 *st = s_rstage + wave * 256u;
+                const int sw = (rk >> 1) & 3;
+                st[rk * 4 + (0 ^ sw)] = so.q0; st[rk * 4 + (1 ^ sw)] = so.q1; st[rk * 4 + (2 ^ sw)] = so.q2; st[rk * 4 + (3 ^ sw)] = so.q3;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint4 *dst = reinterpret_cast<uint4 *>(g.recs + t0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int c = rk + j * np, rr = c >> 2; dst[c] = st[rr * 4 + ((c & 3) ^ ((rr >> 1) & 3))]; }
+            } else {
+                uint4 *dst = reinterpret_cast<uint4 *>(g.recs + t);
+                dst[0] = so.q0; dst[1] = so.q1; dst[2] = so.q2; dst[3] = so.q3;
+            }
+            if constexpr (K > 0) {
+                float *o = g.vary + (size_t)t * (3 * K);
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) o[sl * K + k] = so.d0 == sl ? ctx[0][k] : (so.d1 == sl ? ctx[1][k] : ctx[2][k]);
+            }
+        }
+        if (t < hi) g.pbox[t] = my_pbox;
+        bin_one<false>(a, s_hist, my_pbox, t - (uint32_t)lane, lane, put);    // every wave, every lane (empty boxes count nothing)
+        __syncthreads();
+        const uint32_t ncl = s_ncl[grp];
+        for (uint32_t e = (uint32_t)wg; e < ncl; e += 4u) {                   // the block's clipped inputs, one wave per triangle
+            const uint32_t en = s_cl[grp * GEOM_BLOCK + e];
+            const uint32_t fb = fbase + (en >> 8);
+            const uint4 pbf = clip_triangle_wave<VS>(g, u, blk * GEOM_BLOCK + (en & 255u), fb, lane, s_cxy[wave], s_ckey[wave], s_cv[wave]);
+            bin_one<false>(a, s_hist, pbf, g.ntris + fb, lane, put);
+        }
+        __syncthreads();
+        if (tin == 0) s_ncl[grp] = 0u;   // (ordered before the next round's use by the barriers of its scans)
+    }
+    __syncthreads();
+    uint32_t base, total;
+    bin_reserve_publish(a, s_hist, ntiles, seg + (size_t)gi * (ntiles + 1), bslot, s_w, &s_base, lane, wave, base, total);
+    put.region = base;
+    bin_walk<true>(a, s_hist, g.pbox, lo, hi, lane, wave, put);
+    for (uint32_t k = 0; k < rounds * GB_GROUPS; ++k) {
+        const uint2 fr = s_fanr[k];
+        if (fr.y && fr.x + fr.y <= g.fan_cap) bin_walk<true>(a, s_hist, g.pbox, g.ntris + fr.x, g.ntris + fr.x + fr.y, lane, wave, put);
+    }
+    __syncthreads();
+    const uint32_t nstaged = min(total, stage_cap);
+    for (uint32_t j = threadIdx.x; j < nstaged; j += BIN_WG)
+        if (base + j < a.bin_cap) a.bins[base + j] = s_bstage[j];
+    // count this workgroup in; the last one scans the block sums of the whole draw
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&g.cnt->done_ctr, 1u) == G - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+        if (threadIdx.x == 0) g.cnt->done_ctr = 0u;
+        geom_scan<true>(g.block_sums, nblocks, g.cnt, g.fslot, g.fan_cap);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -704,11 +886,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     __shared__ uint32_t s_base;
     const uint32_t g = blockIdx.x, G = gridDim.x - (uint32_t)do_scan;
     for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) s_hist[t] = 0u;
-    if (g == 0 && threadIdx.x == 0) { // the other slot belongs to the previous draw, which has drained
-        a.cnt->bin_entries_frame += a.cnt->seg_total[slot ^ 1];
-        a.cnt->seg_total[slot ^ 1] = 0ull;
-        a.cnt->ent_cursor[slot ^ 1] = 0u;
-    }
+    if (g == 0 && threadIdx.x == 0) bin_bookkeeping(a.cnt, slot);
     __syncthreads();
     const uint32_t n = draw_slots(a.cnt, fslot, fan_cap);
     uint32_t chunk = (n + G - 1) / G;

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
 // ---------------------------------------------------------------------------------------------
 // k_raster_span
 // ---------------------------------------------------------------------------------------------
-constexpr int SPAN_SAFE = 8192; // |spi| and window coordinates up to this keep every edge value < 2^30
+constexpr int SPAN_SAFE = 8191; // |spi| and window coordinates up to this keep every edge value < 2^30 (and twice an edge delta in 16 bits)
 constexpr int SPAN_BATCH = 32;  // triangles per wavefront batch (staging sized for 8 workgroups per CU)
 #ifndef FRR_SPAN_CULL
 #define FRR_SPAN_CULL 32
@@ -327,6 +327,14 @@ constexpr int SPAN_CULL = FRR_SPAN_CULL; // bin entries culled per step (<= 64):
 #ifndef FRR_SPAN_AQ_MIN
 #define FRR_SPAN_AQ_MIN 1
 #endif
+#ifndef FRR_LIGHT_NW
+#define FRR_LIGHT_NW 3
+#endif
+#ifndef FRR_LIGHT_B
+#define FRR_LIGHT_B 32
+#endif
+constexpr int LIGHT_NW = FRR_LIGHT_NW; // waves per tile of the shape for lightly loaded tiles, and the triangles a wave stages there
+constexpr int LIGHT_B = FRR_LIGHT_B;
 constexpr int SPAN_AQ_MIN = FRR_SPAN_AQ_MIN; // survivors a wave collects before it rasterizes them (1: after every cull step)
 
 // wave64 inclusive prefix sum on the DPP network (row_shr within 16-lane rows, then row broadcasts)
@@ -370,28 +378,46 @@ __device__ __forceinline__ void seg_advance(uint32_t h_lo, uint32_t h_hi, int &b
     base += __popc(h_lo) + __popc(h_hi);
 }
 
-// per-triangle integers and reciprocals staged for the span phase (48 bytes)
+// Per-triangle data of the span phase (48 bytes).  Row `row` of the triangle's bbox-in-tile is covered by the dx in
+// [lo, hi) that satisfy A*dx >= N(row) on all three edges, N(row) = (thr + 1 - E at the bbox origin) - B*row, thr = -1
+// for top-left edges else 0 (renderer.rs:329-341).  Each edge is stored in the form the row lanes evaluate without
+// branches: M(row) = m + k*row, q = floor(M / D), and
+//   A > 0:  dx >= ceil(N/A) = floor((N + A - 1)/A)      m = n + A - 1,  k = -B,  D = A,   q bounds lo
+//   A < 0:  dx <= floor(-N/|A|)                         m = -n,         k = B,   D = |A|, q + 1 bounds hi
+//   A = 0:  all dx if N <= 0, none otherwise            m = 1 - 2n,     k = 2B,  D = 1,   "reciprocal" 64: M is odd, so
+//           the quotient is >= 39 (hi unchanged: a row has at most 32 pixels) or <= -1 (hi <= 0)
 struct alignas(16) SpanTri {
-    int32_t n01, n12, n20;     // (thr + 1) - E at the bbox-in-tile origin, thr = -1 for top-left edges else 0
+    int32_t m01, m12, m20;     // M at row 0
     uint32_t zub;              // zkey of an upper bound of rhw over the triangle
-    uint32_t ab01, ab12, ab20; // A (low 16, signed) | B (high 16, signed)
-    uint32_t misc;             // bx0l:5 | by0l:5 <<5 | bw:6 <<10
-    float r01, r12, r20, pad;  // v_rcp_f32 of |A| per edge (0 for A == 0)
+    uint32_t kd01, kd12, kd20; // k (low 16, signed) | D (high 16)
+    uint32_t misc;             // bx0l:5 | by0l:5 <<5 | bw:6 <<10 | (A > 0) per edge <<16
+    float r01, r12, r20, pad;  // v_rcp_f32 of D per edge
 };
-
-// edge_bound with the reciprocal of |A| supplied: dx in [lo,hi) with A*dx >= N
-__device__ __forceinline__ void edge_bound_pre(int N, int A, float rD, int &lo, int &hi)
+struct SpanEdge { int32_t m; uint32_t kd; float r; uint32_t pos; };
+__device__ __forceinline__ SpanEdge span_edge_setup(int A, int B, int n)
 {
+    SpanEdge e;
     const int D = A > 0 ? A : -A;
-    const int M = A > 0 ? N + D - 1 : -N;           // A>0: dx >= ceil(N/A) = floor(M/D); A<0: dx <= floor(M/D)
-    float qf = (float)M * rD;
-    qf = fminf(fmaxf(qf, -2.0f), 40.0f);            // only quotients in [0, 32] matter
-    int q = (int)qf;
+    if (A > 0) { e.m = n + D - 1; e.kd = ((uint32_t)(-B) & 0xFFFFu) | ((uint32_t)D << 16); e.pos = 1u; }
+    else if (A < 0) { e.m = -n; e.kd = ((uint32_t)B & 0xFFFFu) | ((uint32_t)D << 16); e.pos = 0u; }
+    else {
+        const int nc = min(max(n, -(1 << 24)), 1 << 24);   // |B*row| < 2^19: the sign of N survives the clamp
+        e.m = 1 - 2 * nc; e.kd = ((uint32_t)(2 * B) & 0xFFFFu) | (1u << 16); e.pos = 0u;
+    }
+    e.r = A ? __builtin_amdgcn_rcpf((float)D) : 64.0f;      // the 1-ulp reciprocal, once per triangle
+    return e;
+}
+// narrows [lo, hi) by one edge; pmask = -1 for A > 0 else 0.  Only quotients in [0, 32] matter: the float quotient is
+// clamped to [-2, 40] and ONE remainder step makes every in-range quotient exact (out-of-range ones stay out of range).
+__device__ __forceinline__ void span_edge_bound(int m, uint32_t kd, float rD, int pmask, int row, int &lo, int &hi)
+{
+    const int k = (int)(kd << 16) >> 16, D = (int)(kd >> 16);
+    const int M = m + __mul24(k, row);
+    int q = (int)__builtin_amdgcn_fmed3f((float)M * rD, -2.0f, 40.0f);
     const int r = M - __mul24(q, D);
-    q += (r < 0) ? -1 : ((r >= D) ? 1 : 0);         // one correction step makes the in-range quotient exact
-    if (A > 0) lo = max(lo, q);
-    else if (A < 0) hi = min(hi, q + 1);
-    else if (N > 0) hi = 0;
+    q += (r >> 31) + (int)(r >= D);
+    lo = max(lo, q & pmask);                   // (lo >= 0 throughout, so 0 is neutral)
+    hi = min(hi, max(q + 1, pmask & 64));      // (negative bounds become 0: the span is empty either way)
 }
 
 // Hierarchical z: s_hiz[row*4 + seg] = min over the 8 pixels of (row, seg) of the depth part of the
@@ -400,7 +426,10 @@ __device__ __forceinline__ void edge_bound_pre(int N, int A, float rD, int &lo, 
 // Layout of the array hz[HZ_SIZE]: [HZ_SEG + row*4 + seg] 8-pixel row segments, [HZ_BLK + by*4 + bx]
 // 8x8 blocks, [HZ_QUAD + qy*2 + qx] 16x16 quads, [HZ_C4 + row*8 + cell] 4-pixel cells of a row.
 constexpr int DIRECT_MAX = 256;  // records of a tile that are culled straight from registers (k_raster_span) ...
-constexpr int DIRECT_STEPS = 2;  // ... in this many steps per wave (at least DIRECT_MIN lanes each)
+#ifndef FRR_DIRECT_STEPS
+#define FRR_DIRECT_STEPS 2
+#endif
+constexpr int DIRECT_STEPS = FRR_DIRECT_STEPS;  // ... in this many steps per wave (at least DIRECT_MIN lanes each)
 constexpr int DIRECT_MIN = 4;
 constexpr int HZ_SEG = 0, HZ_BLK = 128, HZ_QUAD = 144, HZ_C4 = 148, HZ_SIZE = 404;
 // lane ^ 1 and lane ^ 2 inside each quad of lanes, on the DPP network (no LDS round trip)
@@ -479,7 +508,7 @@ template <int NW, int B> struct SpanLds {
 template <int K, int PS, bool COUNT, int NW, int OCC>
 __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevUniforms u, int win_safe)
 {
-    constexpr int B = (OCC >= 8 || NW <= 3 || NW >= 16) ? 16 : SPAN_BATCH; // staged triangles per wave (LDS budget: 8 workgroups per CU; 64 KiB of static LDS at NW = 16)
+    constexpr int B = NW <= 3 ? LIGHT_B : (OCC >= 8 || NW >= 16) ? 16 : SPAN_BATCH; // staged triangles per wave (LDS budget: 8 workgroups per CU; 64 KiB of static LDS at NW = 16)
     constexpr bool TEXTURED = PS == FRR_PS_PHONG || PS == FRR_PS_BLINN;
     using L = SpanLds<NW, B>;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[L::bytes(TEXTURED)];
@@ -527,7 +556,18 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         }
         const uint32_t inc = wave_incl_scan_dpp(cn);
         if (lane == 63 && w < 4) s_w4[w] = inc;
-        if (NW < 4 && threadIdx.x == 0) s_w4[3] = 0u; // (the host keeps nseg <= NW * 64)
+        // three waves: segments 192..255 are a second column read of wave 0 (the host keeps nseg <= 256 then, else <= NW * 64)
+        uint32_t s0x = 0, cnx = 0, incx = 0;
+        if (NW == 3 && w == 0) {
+            if (192u + (uint32_t)lane < a.nseg) {
+                const uint32_t *r = a.seg + (size_t)(192 + lane) * ((size_t)gridDim.x + 1) + c.ltile;
+                s0x = r[0];
+                cnx = r[1] - s0x;
+            }
+            incx = wave_incl_scan_dpp(cnx);
+            if (lane == 63) s_w4[3] = incx;
+        }
+        if (NW < 3 && threadIdx.x == 0) { s_w4[2] = 0u; s_w4[3] = 0u; }
         __syncthreads();
         const uint32_t w0 = s_w4[0], w1 = s_w4[1], w2 = s_w4[2], w3 = s_w4[3];
         const uint32_t total = __builtin_amdgcn_readfirstlane((w0 + w1) + (w2 + w3)); // wave-uniform, and the compiler should know
@@ -536,7 +576,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             s_segpre[threadIdx.x] = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u) + inc - cn;
             s_segsrc[threadIdx.x] = s0;
         }
-        for (int i = threadIdx.x + NW * 64; i < BIN_MAX_G; i += NW * 64) { s_segpre[i] = total; s_segsrc[i] = 0u; } // NW < 4 only
+        if (NW == 3 && w == 0) { s_segpre[192 + lane] = (w0 + w1) + w2 + incx - cnx; s_segsrc[192 + lane] = s0x; }
+        if (NW < 3) for (int i = threadIdx.x + NW * 64; i < BIN_MAX_G; i += NW * 64) { s_segpre[i] = total; s_segsrc[i] = 0u; }
         if (threadIdx.x == 0) {
             s_segpre[BIN_MAX_G] = total;
             // where this tile's near-first copy goes: its own fixed slot of bins2, or -- a tile hotter than
@@ -739,18 +780,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             const int e12 = __mul24(A12, bx0 - p1x) + __mul24(B12, by0 - p1y);
             const int e20 = __mul24(A20, bx0 - p2x) + __mul24(B20, by0 - p2y);
             // accept E > thr, thr = -1 for top-left edges, else 0 (:333-341): a row needs A*dx >= (thr + 1 - E_row)
+            const SpanEdge g01 = span_edge_setup(A01, B01, (int)((q3.w >> 1) & 1u) - e01);
+            const SpanEdge g12 = span_edge_setup(A12, B12, (int)((q3.w >> 2) & 1u) - e12);
+            const SpanEdge g20 = span_edge_setup(A20, B20, (int)((q3.w >> 3) & 1u) - e20);
             SpanTri t;
-            t.n01 = (int)((q3.w >> 1) & 1u) - e01;
-            t.n12 = (int)((q3.w >> 2) & 1u) - e12;
-            t.n20 = (int)((q3.w >> 3) & 1u) - e20;
+            t.m01 = g01.m; t.m12 = g12.m; t.m20 = g20.m;
             t.zub = en.y;                        // zkey of an upper bound of rhw over the triangle (cull_zub)
-            t.ab01 = ((uint32_t)A01 & 0xFFFFu) | ((uint32_t)B01 << 16);
-            t.ab12 = ((uint32_t)A12 & 0xFFFFu) | ((uint32_t)B12 << 16);
-            t.ab20 = ((uint32_t)A20 & 0xFFFFu) | ((uint32_t)B20 << 16);
-            t.misc = (uint32_t)(bx0 - c.ax0) | ((uint32_t)(by0 - c.ay0) << 5) | ((uint32_t)(bx1 - bx0) << 10);
-            t.r01 = A01 ? __builtin_amdgcn_rcpf((float)abs(A01)) : 0.0f;   // the span quotients' 1-ulp reciprocals, once per triangle
-            t.r12 = A12 ? __builtin_amdgcn_rcpf((float)abs(A12)) : 0.0f;
-            t.r20 = A20 ? __builtin_amdgcn_rcpf((float)abs(A20)) : 0.0f;
+            t.kd01 = g01.kd; t.kd12 = g12.kd; t.kd20 = g20.kd;
+            t.misc = (uint32_t)(bx0 - c.ax0) | ((uint32_t)(by0 - c.ay0) << 5) | ((uint32_t)(bx1 - bx0) << 10) |
+                     (g01.pos << 16) | (g12.pos << 17) | (g20.pos << 18);
+            t.r01 = g01.r; t.r12 = g12.r; t.r20 = g20.r;
             t.pad = 0.0f;
             s_tri[w][trank] = t;
             s_fa[w][trank] = make_float4(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y));
@@ -785,13 +824,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
                 const SpanTri ti = s_tri[w][j];
                 const int row = sp.off;
                 const int bwj = (int)((ti.misc >> 10) & 63u);
-                const int A01 = (int)(ti.ab01 << 16) >> 16, B01 = (int)ti.ab01 >> 16;
-                const int A12 = (int)(ti.ab12 << 16) >> 16, B12 = (int)ti.ab12 >> 16;
-                const int A20 = (int)(ti.ab20 << 16) >> 16, B20 = (int)ti.ab20 >> 16;
                 int lo = 0, hi = bwj;
-                edge_bound_pre(ti.n01 - __mul24(B01, row), A01, ti.r01, lo, hi);
-                edge_bound_pre(ti.n12 - __mul24(B12, row), A12, ti.r12, lo, hi);
-                edge_bound_pre(ti.n20 - __mul24(B20, row), A20, ti.r20, lo, hi);
+                span_edge_bound(ti.m01, ti.kd01, ti.r01, (int)(ti.misc << 15) >> 31, row, lo, hi);
+                span_edge_bound(ti.m12, ti.kd12, ti.r12, (int)(ti.misc << 14) >> 31, row, lo, hi);
+                span_edge_bound(ti.m20, ti.kd20, ti.r20, (int)(ti.misc << 13) >> 31, row, lo, hi);
                 len = max(hi - lo, 0);
                 xl = (int)(ti.misc & 31u) + lo;
                 yl = (int)((ti.misc >> 5) & 31u) + row;

@@ -291,7 +291,7 @@ class Renderer:
         self._check(self._lib.frr_event_elapsed_ms(self._ctx, a, b, C.byref(ms)))
         return float(ms.value)
 
-    KERNELS = ("k_clear", "k_geom", "k_geom_scan", "k_unused", "k_bin_count",
+    KERNELS = ("k_clear", "k_geom", "k_geom_scan", "k_geom_bin", "k_bin_count",
                "k_tile_scan", "k_bin_fill", "k_raster", "k_bin_seg")
 
     def profile_enable(self, on=True, kernels=None, period=1):

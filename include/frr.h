@@ -196,7 +196,7 @@ int frr_event_record(frr_ctx *ctx, int slot);
 int frr_event_elapsed_ms(frr_ctx *ctx, int a, int b, float *ms);
 /* per-kernel accumulated device time (ms) and launch count since frr_profile_reset.  `mask`:
  * 0 = off, -1 = every kernel, else OR of (1 << index) with index in the order k_clear,
- * k_geom, k_geom_scan, k_unused, k_bin_count, k_tile_scan, k_bin_fill, k_raster,
+ * k_geom, k_geom_scan, k_geom_bin, k_bin_count, k_tile_scan, k_bin_fill, k_raster,
  * k_bin_seg.  A profiled launch is bracketed by two HIP events on the ctx stream. */
 int frr_profile_enable(frr_ctx *ctx, int mask);
 /* bracket only every `period`-th launch of each selected kernel (default 1): an event pair costs the

@@ -201,3 +201,55 @@ def test_fan_capacity_overflow_is_reported_then_recovers(oracle):
     np.testing.assert_array_equal(t, f.tri_id)
     np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
     assert r.stats()["tris_setup"] == f.counters.tris_setup
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"])
+@pytest.mark.parametrize("scene", ["clip_heavy", "phong", "many_rounds"])
+def test_fused_and_separate_geometry_binning_agree_with_oracle(oracle, monkeypatch, fuse, scene):
+    """FRR_FUSE=1 makes frr_draw set up and bin in ONE launch (k_geom_bin) when it can; the default keeps the two kernels
+    (k_geom_single + k_bin_seg) that frr_geometry + frr_raster always use.  Both must give the oracle's bits: setup
+    records, ids, depth, colour -- with clipped fans, a textured mesh (K = 8 varyings through the fused kernel's staging)
+    and a mesh of several rounds per workgroup (600k triangles)."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    monkeypatch.setenv("FRR_FUSE", fuse)
+    if scene == "phong":
+        W, H = 320, 200
+        mesh = scenes.displaced_sphere(n=60)
+        tex = scenes.checker_texture(64, 8)
+        eye, at, up, fovy, aspect, zn, zf = scenes.demo_camera(W, H)
+        r = fr.Renderer(W, H)
+        r.set_texture(0, tex)
+        r.set_uniforms(view=fr.set_look_at(eye, at, up), proj=fr.set_perspective(fovy, aspect, zn, zf), view_pos=eye, texture_slot=0)
+        f = oracle.Frame(W, H)
+        u = oracle.make_uniforms(view=oracle.set_look_at(eye, at, up), proj=oracle.set_perspective(fovy, aspect, zn, zf),
+                                 view_pos=eye, tex=oracle.Texture(tex))
+        vs, ps, ovs, ops = fr.VS_PHONG, fr.PS_BLINN, oracle.VS_PHONG, oracle.PS_BLINN
+    else:
+        W, H = (300, 170) if scene == "clip_heavy" else (640, 360)
+        n = 30000 if scene == "clip_heavy" else 600000
+        mesh = scenes.random_clip_triangles(n, W if scene == "clip_heavy" else 4 * W, H if scene == "clip_heavy" else 4 * H,
+                                            seed=61, spread=1.25 if scene == "clip_heavy" else 1.0)
+        r = fr.Renderer(W, H)
+        f = oracle.Frame(W, H)
+        u = oracle.make_uniforms()
+        vs, ps, ovs, ops = fr.VS_CLIP, fr.PS_DEPTH, oracle.VS_CLIP, oracle.PS_DEPTH
+    m = r.upload_mesh(mesh, vs)
+    for _ in range(2):                      # twice: the per-draw slots alternate
+        r.clear()
+        r.draw(m, ps)
+    f.clear()
+    setup = f.draw(mesh, ovs, ops, u, keep_setup=scene != "many_rounds")
+    c, d, t = r.readback()
+    np.testing.assert_array_equal(t, f.tri_id)
+    np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+    if scene == "phong":
+        np.testing.assert_array_equal(c, f.color)
+    st = r.stats()
+    assert st["tris_setup"] == f.counters.tris_setup and st["overflow"] == 0
+    if scene != "many_rounds":
+        g = r.setup_triangles()
+        assert g.shape[0] == setup.shape[0]
+        np.testing.assert_array_equal(g["spi"], setup["spi"])
+        np.testing.assert_array_equal(g["spf"].view(np.uint32), setup["spf"].view(np.uint32))
+        np.testing.assert_array_equal(g["rhw"].view(np.uint32), setup["rhw"].view(np.uint32))
