@@ -23,7 +23,6 @@ HIPCC_FLAGS = [
 ]
 
 FRR_OK, FRR_ERR_INVALID, FRR_ERR_HIP, FRR_ERR_NOMEM, FRR_ERR_UNSUPPORTED, FRR_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
-FRR_WARN_NAN = 1
 VS_CLIP, VS_CLIP_COLOR, VS_PHONG, VS_GOURAUD = 0, 1, 2, 3
 PS_DEPTH, PS_FLAT, PS_COLOR, PS_PHONG, PS_BLINN = 0, 1, 2, 3, 4
 MAX_VARYINGS = 16

@@ -212,7 +212,6 @@ int check_frame_counters(frr_ctx *c, Counters *host)
         if (h.overflow & 1u) c->fan_hint = (size_t)h.need_fans + h.need_fans / 8 + 1024;
         return fail(c, FRR_ERR_CAPACITY, "device work list overflowed; capacity grown, re-issue the frame");
     }
-    if (h.frag_nan) { c->err = "the frame contained NaN-depth fragments: pixels they cover may differ from the reference (renderer.rs:363-366)"; return FRR_WARN_NAN; }
     return FRR_OK;
 }
 
@@ -858,7 +857,7 @@ int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uin
         return fail(c, FRR_ERR_INVALID, "the setup list of a partitioned frr_draw holds only this rank's triangles; use frr_geometry to read back the full Vec<[Vertex;3]>");
     { int rcs = settle(c); if (rcs != FRR_OK) return rcs; }
     Counters h;
-    const int rc_frame = check_frame_counters(c, &h);   // (FRR_WARN_NAN is passed on with the data)
+    const int rc_frame = check_frame_counters(c, &h);
     if (rc_frame < FRR_OK) return rc_frame;
     *ntris = h.n_emit;
     if (!out) return rc_frame;

@@ -60,6 +60,14 @@ FRR_HD uint32_t zkey(float f)
     uint32_t u = f2u(f + 0.0f); // -0.0 + 0.0 == +0.0 (round-to-nearest); every other value unchanged
     return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
 }
+// NaN depths (renderer.rs:363-366: `rhw < depth` is false when either side is NaN, so a NaN fragment always passes and
+// the next fragment on a NaN pixel always passes).  In pixel keys: a NaN already IN the depth buffer is the lowest key,
+// everything beats it; a NaN FRAGMENT takes the highest key, so that after the main pass the pixel holds the id of its
+// LAST NaN fragment, and the tile kernels' second pass (tile_nan_*) then keeps only the fragments submitted after it.
+// Neither value is the image of a non-NaN float (those lie in [0x007FFFFF, 0xFF800000]).
+constexpr uint32_t ZKEY_NAN_BELOW = 0u, ZKEY_NAN_FRAG = 0xFFFFFFFFu;
+FRR_HD uint32_t zkey_depth(float d) { return d == d ? zkey(d) : ZKEY_NAN_BELOW; }
+FRR_HD uint32_t zkey_frag(float rhw) { return rhw == rhw ? zkey(rhw) : ZKEY_NAN_FRAG; }
 FRR_HD float zkey_decode(uint32_t k)
 {
     return u2f((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);

@@ -108,7 +108,7 @@ __device__ __forceinline__ void tile_load_keys(const RasterArgs &a, const TileCt
 {
     if (a.fused_clear && c.tw == TILE && c.th == TILE) {
         // a full tile of a draw that carries the frame's clear: one constant, 32 bytes per lane and store
-        const uint32_t k = zkey(a.clear_depth);
+        const uint32_t k = zkey_depth(a.clear_depth);
         uint4 *p = reinterpret_cast<uint4 *>(s_key);
         for (int i = threadIdx.x; i < TILE_PX / 2; i += (int)blockDim.x) p[i] = make_uint4(0u, k, 0u, k);
         return;
@@ -117,7 +117,7 @@ __device__ __forceinline__ void tile_load_keys(const RasterArgs &a, const TileCt
         const int x = i & (TILE - 1), y = i >> 5;
         unsigned long long k = oob;
         if (x < c.tw && y < c.th)
-            k = (unsigned long long)zkey(a.fused_clear ? a.clear_depth : a.depth[(size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x)]) << 32;
+            k = (unsigned long long)zkey_depth(a.fused_clear ? a.clear_depth : a.depth[(size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x)]) << 32;
         s_key[i] = k;
     }
 }
@@ -242,8 +242,13 @@ __device__ __forceinline__ void tile_resolve_depth4(const RasterArgs &a, const T
 
 // Brute-force sweep of ONE triangle (wave-uniform index t) by the whole wave: every pixel of
 // bbox-in-tile is tested with the wrapping-i32 edge functions of renderer.rs:329-341.
+// NANPASS = false: the main pass; a NaN fragment takes the key ZKEY_NAN_FRAG and raises *nanflag.
+// NANPASS = true: the second pass of a tile that saw NaN fragments (tile_nan_begin): only pixels with nanL != 0 take
+// part, and there only the non-NaN fragments submitted after the pixel's last NaN fragment (id > nanL).
+template <bool NANPASS = false>
 __device__ __forceinline__ void sweep_triangle(const RasterArgs &a, const TileCtx &c, uint32_t t, uint32_t key_id, int lane,
-                                               unsigned long long *s_key, uint32_t &n_cov, uint32_t &n_nan)
+                                               unsigned long long *s_key, uint32_t &n_cov, uint32_t &n_nan, uint32_t *nanflag,
+                                               const uint32_t *nanL = nullptr)
 {
     const RasterRec *__restrict__ r = a.recs + t;
     const int p0x = r->p[0], p0y = r->p[1], p1x = r->p[2], p1y = r->p[3], p2x = r->p[4], p2y = r->p[5];
@@ -276,17 +281,43 @@ __device__ __forceinline__ void sweep_triangle(const RasterArgs &a, const TileCt
         const int E01 = (int)(E01o + A01 * (uint32_t)dx + B01 * (uint32_t)dy);
         const int E12 = (int)(E12o + A12 * (uint32_t)dx + B12 * (uint32_t)dy);
         const int E20 = (int)(E20o + A20 * (uint32_t)dx + B20 * (uint32_t)dy);
-        const bool covered = (E01 > thr01) & (E12 > thr12) & (E20 > thr20);
-        n_cov += (uint32_t)__popcll(__ballot(covered));
+        bool covered = (E01 > thr01) & (E12 > thr12) & (E20 > thr20);
+        const int cx = bx0 + dx, cy = by0 + dy;
+        const int pix = (cy - c.ay0) * TILE + (cx - c.ax0);
+        if (NANPASS) {
+            const uint32_t last_nan = nanL[pix];
+            covered = covered && last_nan != 0u && key_id > last_nan;
+        } else {
+            n_cov += (uint32_t)__popcll(__ballot(covered));
+        }
         if (covered) {
-            const int cx = bx0 + dx, cy = by0 + dy;
             Frag f = frag_eval(s0x, s0y, s1x, s1y, s2x, s2y, r0, r1, r2, cx, cy);
             if (f.valid) {
-                if (f.rhw != f.rhw) ++n_nan;
-                const unsigned long long key = ((unsigned long long)zkey(f.rhw) << 32) | idlow;
-                atomicMax(&s_key[(cy - c.ay0) * TILE + (cx - c.ax0)], key);
+                const bool isnan = f.rhw != f.rhw;
+                if (NANPASS) {
+                    if (!isnan) atomicMax(&s_key[pix], ((unsigned long long)zkey(f.rhw) << 32) | idlow);
+                } else {
+                    if (isnan) { ++n_nan; *nanflag = 1u; }
+                    atomicMax(&s_key[pix], ((unsigned long long)zkey_frag(f.rhw) << 32) | idlow);
+                }
             }
         }
+    }
+}
+
+// First half of the NaN pass of a tile whose main pass saw NaN fragments: a pixel whose key carries ZKEY_NAN_FRAG holds
+// the id of its LAST NaN fragment.  That id moves to nanL[pixel] (0 elsewhere) and the key becomes {ZKEY_NAN_BELOW, id}:
+// the NaN fragment owns the pixel unless a later-submitted fragment covers it, and the first such fragment passes
+// whatever its depth (renderer.rs:363-366).  The caller then sweeps all records of the tile again with NANPASS = true.
+// Pixels that saw no NaN fragment already hold their final key.
+__device__ __forceinline__ void tile_nan_begin(const TileCtx &c, unsigned long long *s_key, uint32_t *nanL)
+{
+    for (int i = threadIdx.x; i < TILE_PX; i += (int)blockDim.x) {
+        const int x = i & (TILE - 1), y = i >> 5;
+        const unsigned long long k = s_key[i];
+        const bool nanpix = x < c.tw && y < c.th && (uint32_t)(k >> 32) == ZKEY_NAN_FRAG;
+        nanL[i] = nanpix ? (uint32_t)k : 0u;
+        if (nanpix) s_key[i] = ((unsigned long long)ZKEY_NAN_BELOW << 32) | (unsigned long long)(uint32_t)k;
     }
 }
 
@@ -298,20 +329,32 @@ template <int K, int PS>
 __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
 {
     __shared__ unsigned long long s_key[TILE_PX];
+    __shared__ uint32_t s_nanL[TILE_PX];
+    __shared__ uint32_t s_nanflag;
     const TileCtx c = tile_ctx(a);
     if (c.beg >= c.end) return; // nothing binned here: colour, depth and ids stay as they are
     tile_load_keys(a, c, s_key);
+    if (threadIdx.x == 0) s_nanflag = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t n_cov = 0, n_nan = 0;
     for (uint32_t e = c.beg + wave; e < c.end; e += 4) {
         const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e].x);
-        sweep_triangle(a, c, t, order_id(a.cnt, t), lane, s_key, n_cov, n_nan);
+        sweep_triangle(a, c, t, order_id(a.cnt, t), lane, s_key, n_cov, n_nan, &s_nanflag);
     }
     if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
     if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
     __syncthreads();
+    if (s_nanflag != 0u) { // (uniform: read after the barrier)
+        tile_nan_begin(c, s_key, s_nanL);
+        __syncthreads();
+        for (uint32_t e = c.beg + wave; e < c.end; e += 4) {
+            const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e].x);
+            sweep_triangle<true>(a, c, t, order_id(a.cnt, t), lane, s_key, n_cov, n_nan, nullptr, s_nanL);
+        }
+        __syncthreads();
+    }
     tile_resolve<K, PS>(a, u, c, s_key);
 }
 
@@ -528,6 +571,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
     uint32_t &s_next = *reinterpret_cast<uint32_t *>(s_raw + L::SCAL);
     uint32_t &s_dirty = *reinterpret_cast<uint32_t *>(s_raw + L::SCAL + 4); // keys changed since the hierarchical z was last rebuilt
     uint32_t &s_ebase = *reinterpret_cast<uint32_t *>(s_raw + L::SCAL + 8);
+    uint32_t &s_nanflag = *reinterpret_cast<uint32_t *>(s_raw + L::SCAL + 12); // some fragment of this tile had a NaN rhw: second pass (tile_nan_begin)
+    uint32_t *const s_nanL = reinterpret_cast<uint32_t *>(s_raw + L::U0);      // that pass's per-pixel ids; over the staging, after the main loop
+    static_assert(L::U1 - L::U0 >= TILE_PX * 4, "the NaN pass keeps one u32 per pixel in the staging region");
     uint32_t *const s_w4 = reinterpret_cast<uint32_t *>(s_raw + L::SCAL + 16);
     float *const s_u8 = reinterpret_cast<float *>(s_raw + L::U8);  // (float)i / 255.0f for the texture taps of the resolve
     if (TEXTURED) for (int i = threadIdx.x; i < 256; i += NW * 64) s_u8[i] = (float)i / 255.0f; // ordered by the barriers below
@@ -603,7 +649,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         return a.bins[s_segsrc[g] + (k - s_segpre[g])];
     };
     tile_load_keys(a, c, s_key, ~0ull);
-    if (threadIdx.x == 0) { s_next = 0; s_dirty = 1u; }
+    if (threadIdx.x == 0) { s_next = 0; s_dirty = 1u; s_nanflag = 0u; }
     if (threadIdx.x < 64) s_bkt[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < HZ_SIZE; i += NW * 64) s_hz[i] = 0u; // "nothing can be culled" until the first rebuild lands
     __syncthreads();
@@ -759,7 +805,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             um &= um - 1;
             const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)en.x, src);
             uint32_t ncv = 0;
-            sweep_triangle(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(a.cnt, tu) : order_id(a.cnt, tu), lane, s_key, ncv, n_nan);
+            sweep_triangle(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(a.cnt, tu) : order_id(a.cnt, tu), lane, s_key, ncv, n_nan, &s_nanflag);
             n_cov += ncv;
         }
         const unsigned long long am = __ballot(alive);
@@ -893,8 +939,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
                     const float2 fc = s_fc[w][sj];
                     Frag f = frag_eval(fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w, fc.x, c.ax0 + x, c.ay0 + y);
                     if (f.valid) {
-                        if (f.rhw != f.rhw) ++n_nan;
-                        const unsigned long long key = ((unsigned long long)zkey(f.rhw) << 32) | (unsigned long long)f2u(fc.y);
+                        if (f.rhw != f.rhw) { ++n_nan; s_nanflag = 1u; }
+                        const unsigned long long key = ((unsigned long long)zkey_frag(f.rhw) << 32) | (unsigned long long)f2u(fc.y);
 #ifdef FRR_DEBUG_COUNTERS
                         const unsigned long long old = atomicMax(&s_key[y * TILE + x], key);
                         d_pre += __popcll(__ballot(s_tri[w][sj].zub < (uint32_t)(old >> 32)));
@@ -927,6 +973,28 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
 #endif
     if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
     __syncthreads();
+    if (s_nanflag != 0u) {
+        // NaN fragments (renderer.rs:363-366): the pixels they cover are decided by a second, unculled sweep of ALL the
+        // tile's records -- only what was submitted after a pixel's last NaN fragment counts there (tile_nan_begin)
+        tile_nan_begin(c, s_key, s_nanL);
+        __syncthreads();
+        uint32_t dummy_cov = 0, dummy_nan = 0;
+        if (direct) {
+            unsigned long long m = __ballot(dvalid);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)dent.x, src);
+                sweep_triangle<true>(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(a.cnt, tu) : order_id(a.cnt, tu), lane, s_key, dummy_cov, dummy_nan, nullptr, s_nanL);
+            }
+        } else {
+            for (uint32_t e = c.beg + (uint32_t)w; e < c.end; e += NW) {
+                const uint32_t tu = __builtin_amdgcn_readfirstlane(ents[e].x);
+                sweep_triangle<true>(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(a.cnt, tu) : order_id(a.cnt, tu), lane, s_key, dummy_cov, dummy_nan, nullptr, s_nanL);
+            }
+        }
+        __syncthreads();
+    }
     FRR_T(6);
     if constexpr (PS == FRR_PS_DEPTH) tile_resolve_depth4(a, c, s_key);
     else tile_resolve<K, PS>(a, u, c, s_key, TEXTURED ? s_u8 : nullptr);

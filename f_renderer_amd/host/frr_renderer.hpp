@@ -324,7 +324,7 @@ public:
     frr_ctx *raw() { return ctx_; }
 
 private:
-    // negative status: throw; FRR_WARN_NAN (positive): results were delivered, remembered in last_warning
+    // negative status: throw; a positive one (warning; none defined at present): results were delivered, remembered in last_warning
     void check(int rc) { if (rc < FRR_OK) throw Error(rc, frr_last_error(ctx_)); last_warning = rc; }
 public:
     int last_warning = FRR_OK;

@@ -149,7 +149,7 @@ class Renderer:
             pass
 
     def _check(self, rc):
-        """Negative status: raise.  Positive status (FRR_WARN_NAN): the call delivered its results; remembered in
+        """Negative status: raise.  Positive status (a warning; none is defined at present): the call delivered its results; remembered in
         `last_warning` (None when the latest checked call had nothing to report)."""
         if rc < N.FRR_OK:
             raise FrrError(rc, self._lib.frr_last_error(self._ctx).decode())

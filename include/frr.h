@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FRR_ABI_VERSION 1
+#define FRR_ABI_VERSION 2
 #define FRR_MAX_VARYINGS 16
 #define FRR_MAX_TEXTURES 4
 #define FRR_MAX_OUT_TRIS 19 /* 3 + 18 clip vertices -> 19 fan triangles (renderer.rs:150-171,245-264) */
@@ -34,12 +34,6 @@ extern "C" {
 typedef struct frr_ctx frr_ctx;
 
 typedef enum frr_status {
-    FRR_WARN_NAN = 1,         /* frr_sync / frr_readback / frr_readback_setup: the frame is complete and delivered, but it
-                                 contained fragments whose 1/w interpolated to NaN (frr_stats.frag_nan of them).  In the
-                                 sequential reference such a fragment always passes the depth test and the next fragment
-                                 to cover the pixel then passes too, whatever its depth (renderer.rs:363-366); the tile
-                                 kernels resolve depth order-independently and do NOT reproduce that: pixels covered by
-                                 a NaN fragment may differ from the reference.  Every other pixel is exact. */
     FRR_OK = 0,
     FRR_ERR_INVALID = -1,     /* bad argument (the reference would panic: clamp min>max, OOB index) */
     FRR_ERR_HIP = -2,         /* HIP runtime error / no gfx950 device; see frr_last_error */
@@ -94,7 +88,9 @@ typedef struct frr_stats {
     uint64_t tris_setup;   /* triangles after clip + fan */
     uint64_t bin_entries;  /* (triangle, tile) pairs */
     uint64_t frag_covered; /* pass the edge tests renderer.rs:333-341 (exact only while counting is enabled) */
-    uint64_t frag_nan;     /* NaN rhw fragments (not reproduced: see FRR_WARN_NAN) */
+    uint64_t frag_nan;     /* fragments whose rhw interpolated to NaN; they always pass the depth test and so does the next
+                              fragment on their pixel (renderer.rs:363-366): reproduced exactly, by a second pass over the
+                              tiles that saw one (the NaN bit pattern itself is the device's) */
     uint32_t draws;
     uint32_t overflow;     /* non-zero => this frame is invalid, see FRR_ERR_CAPACITY */
 } frr_stats;

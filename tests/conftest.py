@@ -26,3 +26,14 @@ def oracle():
     from oracle import cref
     cref.lib()
     return cref
+
+
+def assert_depth_equal(got, want, err_msg="depth bits differ"):
+    """Depth buffers must agree bit for bit, except that a NaN only has to be a NaN: which quiet-NaN pattern 0 * inf
+    produces is the property of the machine that ran it (x86 gives 0xFFC00000, gfx950 0x7FC00000), not of the algorithm."""
+    import numpy as np
+    got = np.asarray(got, np.float32).ravel()
+    want = np.asarray(want, np.float32).ravel()
+    gn, wn = np.isnan(got), np.isnan(want)
+    np.testing.assert_array_equal(gn, wn, err_msg=err_msg + " (NaN pixels)")
+    np.testing.assert_array_equal(got.view(np.uint32)[~gn], want.view(np.uint32)[~wn], err_msg=err_msg)

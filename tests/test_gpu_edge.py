@@ -3,6 +3,7 @@ capacity overflow + re-issue, global-atomic binning fallback, device-bound meshe
 empty / degenerate inputs, non-square textures, several texture slots."""
 import numpy as np
 import pytest
+from .conftest import assert_depth_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -43,8 +44,6 @@ def test_global_atomic_binning_fallback(oracle, monkeypatch):
     W, H = 300, 200
     tris = scenes.random_clip_triangles(9000, W, H, seed=4, spread=1.25, w_jitter=0.6)   # incl. huge fans
     f = _oracle_depth(oracle, tris, W, H)
-    if f.counters.frag_nan:
-        pytest.skip("NaN rhw")
     r = fr.Renderer(W, H)
     r.clear()
     r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
@@ -212,10 +211,9 @@ def test_vertex_sort_near_ties_and_axes(oracle):
     np.testing.assert_array_equal(g["spi"], setup["spi"])
     np.testing.assert_array_equal(g["spf"].view(np.uint32), setup["spf"].view(np.uint32))
     np.testing.assert_array_equal(g["rhw"].view(np.uint32), setup["rhw"].view(np.uint32))
-    if not f.counters.frag_nan:
-        _, d, t = r.readback()
-        np.testing.assert_array_equal(t, f.tri_id)
-        np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+    _, d, t = r.readback()
+    np.testing.assert_array_equal(t, f.tri_id)
+    assert_depth_equal(d, f.depth)
 
 
 @pytest.mark.parametrize("slot", [1, 16])
@@ -266,10 +264,9 @@ def test_clustered_clipped_triangles(oracle):
     assert g.shape[0] == setup.shape[0]
     np.testing.assert_array_equal(g["spi"], setup["spi"])
     np.testing.assert_array_equal(g["rhw"].view(np.uint32), setup["rhw"].view(np.uint32))
-    if not f.counters.frag_nan:
-        _, d, t = r.readback()
-        np.testing.assert_array_equal(t, f.tri_id)
-        np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+    _, d, t = r.readback()
+    np.testing.assert_array_equal(t, f.tri_id)
+    assert_depth_equal(d, f.depth)
 
 
 @pytest.mark.parametrize("blocked", [False, True])
@@ -306,39 +303,91 @@ def test_owned_rows_are_what_a_partitioned_draw_writes(oracle, world, blocked):
     assert r.owned_rows((0, 0)) == []
 
 
-def test_nan_depth_fragments_are_reported(oracle):
-    """renderer.rs:363-366: a fragment whose 1/w interpolates to NaN always passes the depth test and the next fragment
-    on that pixel then passes too.  The tile kernels do not reproduce that order dependence; they count such fragments
-    and frr_readback / frr_sync return FRR_WARN_NAN with the (complete) frame, so a caller cannot miss it.  The scene: a
-    screen-filling quad, a clipped triangle with a vertex at x = 3e38 (its screen position overflows to inf, so every
-    fragment of its fan interpolates inf * 0), and a nearer triangle on top."""
+NAN_TRIS = np.array([
+    [(-0.9, -0.9, 0.5, 1), (0.9, -0.9, 0.5, 1), (0.9, 0.9, 0.5, 1)],
+    [(-0.9, -0.9, 0.5, 1), (0.9, 0.9, 0.5, 1), (-0.9, 0.9, 0.5, 1)],
+    [(3e38, 0.2, 0.5, 1), (-0.5, -0.5, 0.5, 1), (-0.5, 0.6, 0.5, 1)],    # clipped; a vertex's screen x overflows to inf: every fragment of its fan is 0 * inf
+    [(-0.3, -0.3, 1.0, 2), (0.7, -0.3, 1.0, 2), (0.2, 0.8, 1.0, 2)],      # farther (rhw 0.5), submitted AFTER the NaN fan: passes on the NaN pixels all the same
+    [(-0.6, -0.1, 0.5, 4), (0.1, -0.1, 0.5, 4), (-0.2, 0.5, 0.5, 4)],     # farther still (rhw 0.25): must lose against the previous one again
+], np.float32)
+
+
+@pytest.mark.parametrize("path", ["span", "sweep", "span16"])
+def test_nan_depth_fragments_follow_the_sequential_rule(oracle, monkeypatch, path):
+    """renderer.rs:363-366: `if rhw < depth { continue }` is false when either side is NaN, so a fragment whose 1/w
+    interpolates to NaN always passes, and the next fragment on that pixel passes too whatever its depth; after that the
+    ordinary test resumes.  The tile kernels resolve depth without order, so a tile that saw a NaN fragment runs a second
+    pass: per pixel only what was submitted after its last NaN fragment counts (tile_nan_begin).  Ids and depths must equal
+    the sequential oracle's, NaN pixels included; then a second draw on top of the NaN depths left in the buffer, and a
+    clean frame."""
     import f_renderer_amd as fr
     from f_renderer_amd import scenes
+    if path == "sweep":
+        monkeypatch.setenv("FRR_RASTER", "sweep")
+    if path == "span16":
+        monkeypatch.setenv("FRR_RASTER_NW", "16")
     W, H = 160, 120
-    tris = np.array([
-        [(-0.9, -0.9, 0.5, 1), (0.9, -0.9, 0.5, 1), (0.9, 0.9, 0.5, 1)],
-        [(-0.9, -0.9, 0.5, 1), (0.9, 0.9, 0.5, 1), (-0.9, 0.9, 0.5, 1)],
-        [(3e38, 0.2, 0.5, 1), (-0.5, -0.5, 0.5, 1), (-0.5, 0.6, 0.5, 1)],
-        [(-0.3, -0.3, 1.0, 2), (0.7, -0.3, 1.0, 2), (0.2, 0.8, 1.0, 2)],
-    ], np.float32)
+    order = [0, 1, 2, 3, 4]
+    for trial in range(3):
+        tris = NAN_TRIS[order]
+        f = oracle.Frame(W, H)
+        f.clear()
+        f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
+        assert f.counters.frag_nan > 0 and (order[-1] != 2 or np.isnan(f.depth).any())
+        r = fr.Renderer(W, H)
+        r.clear()
+        r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
+        _, d, t = r.readback()
+        assert r.last_warning is None
+        st = r.stats()
+        assert st["frag_nan"] == f.counters.frag_nan and st["tris_setup"] == f.counters.tris_setup and st["frag_covered"] == f.counters.frag_covered
+        np.testing.assert_array_equal(t, f.tri_id)
+        assert_depth_equal(d, f.depth)
+        # a second draw over whatever the first left (NaN depths when the NaN fan came last): no clear in between
+        more = scenes.random_clip_triangles(300, W, H, seed=17 + trial)
+        f.draw(more, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms(), tri_id_base=int(f.counters.tris_setup))
+        r.draw(r.upload_mesh(more, fr.VS_CLIP), fr.PS_DEPTH)
+        _, d, t = r.readback()
+        np.testing.assert_array_equal(t, f.tri_id)
+        assert_depth_equal(d, f.depth)
+        r.close()
+        order = [[3, 4, 0, 1, 2], [2, 0, 3, 1, 4]][trial % 2]   # NaN fan last (it owns its pixels, depth NaN); NaN fan first
+
+
+def test_nan_depth_fragments_shaded_and_many_tiles(oracle):
+    """The same rule through a shaded draw (the resolve re-evaluates the owner: NaN varyings quantise to 0 as Rust's
+    `as u8` does) and with NaN fans sprinkled over a frame of many tiles, records enough per tile for the near-first
+    copy (the second pass walks it) as well as for the register path."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H = 320, 224
+    rng = np.random.default_rng(8)
+    base = scenes.random_clip_triangles(40000, W, H, seed=23)
+    bad = np.repeat(NAN_TRIS[2:3], 40, axis=0).copy()
+    bad[:, 1:, 0] += rng.uniform(-0.4, 1.2, (40, 1)).astype(np.float32)
+    bad[:, 1:, 1] += rng.uniform(-0.4, 0.4, (40, 1)).astype(np.float32)
+    tris = np.concatenate([base[:20000], bad[:20], base[20000:], bad[20:]])
     f = oracle.Frame(W, H)
     f.clear()
     f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
-    assert f.counters.frag_nan > 0
+    assert f.counters.frag_nan > 1000
     r = fr.Renderer(W, H)
     r.clear()
     r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
     _, d, t = r.readback()
-    assert r.last_warning == fr.FRR_WARN_NAN
-    st = r.stats()
-    assert st["frag_nan"] > 0 and st["tris_setup"] == f.counters.tris_setup and st["frag_covered"] == f.counters.frag_covered
-    r.sync()
-    assert r.last_warning == fr.FRR_WARN_NAN
-    same = (t == f.tri_id) & (d.view(np.uint32) == f.depth.view(np.uint32))
-    assert same.mean() > 0.5        # only pixels a NaN fragment covers may differ
-    # a clean frame afterwards reports nothing
-    good = scenes.random_clip_triangles(500, W, H, seed=5)
+    np.testing.assert_array_equal(t, f.tri_id)
+    assert_depth_equal(d, f.depth)
+    assert r.stats()["frag_nan"] == f.counters.frag_nan
+    # coloured vertices (VS_CLIP_COLOR: 7 floats per vertex): RGBA8 too
+    col = np.concatenate([tris[:3000], tris[20000:20020]])
+    colv = np.concatenate([col, rng.uniform(0, 1, col.shape[:2] + (3,)).astype(np.float32)], axis=2)
+    f = oracle.Frame(W, H)
+    f.clear()
+    f.draw(colv, oracle.VS_CLIP_COLOR, oracle.PS_COLOR, oracle.make_uniforms())
+    assert f.counters.frag_nan > 0
     r.clear()
-    r.draw(r.upload_mesh(good, fr.VS_CLIP), fr.PS_DEPTH)
-    r.readback()
-    assert r.last_warning is None
+    r.draw(r.upload_mesh(colv, fr.VS_CLIP_COLOR), fr.PS_COLOR)
+    c, d, t = r.readback()
+    np.testing.assert_array_equal(t, f.tri_id)
+    assert_depth_equal(d, f.depth)
+    np.testing.assert_array_equal(c, f.color)
