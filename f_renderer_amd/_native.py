@@ -122,6 +122,7 @@ SIGNATURES = {
     "frr_get_stats": (C.c_int, [C.c_void_p, _P(Stats)]),
     "frr_event_record": (C.c_int, [C.c_void_p, C.c_int]),
     "frr_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_float)]),
+    "frr_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "frr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "frr_profile_set_period": (C.c_int, [C.c_void_p, C.c_uint32]),
     "frr_profile_reset": (C.c_int, [C.c_void_p]),

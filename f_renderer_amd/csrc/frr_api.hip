@@ -56,15 +56,15 @@ struct frr_ctx {
     bool scan_pending = false; // the latest draw's block sums are not scanned yet (geom_scan: by the binning launch, or k_geom_scan)
     bool geom_deferred = false; // frr_draw: the geometry kernel is not launched yet (frr_raster may fuse it with the binning)
     GeomArgs geom_args;         //   ... its arguments
-    bool no_fuse = true;        // FRR_FUSE=1 fuses frr_draw's geometry and binning into one launch (k_geom_bin): parity-tested, but measured
+    bool no_fuse = true;        // option fuse_geometry_binning = 1 fuses frr_draw's geometry and binning into one launch (k_geom_bin): parity-tested, but measured
                                 // 4-7 % slower per frame than the two launches (1024-thread workgroups halve the geometry phase's occupancy)
     bool fuse_attr_set[4] = {false, false, false, false};
     size_t fan_hint = 0;       // fan capacity asked for by a draw that overflowed
-    int bin_g = 0;             // FRR_BIN_G: override the number of binning chunks (dev)
-    uint32_t ent_slot_override = 0; // FRR_ENT_SLOT: per-tile slot of bins2 in records (tests of the overflow arena)
+    int bin_g = 0;             // option bin_chunks: override the number of binning chunks (dev)
+    uint32_t ent_slot_override = 0; // option tile_slot_records: per-tile slot of bins2 in records (tests of the overflow arena)
     // frr_clear is deferred: the first full-window draw of the span kernel performs it inside the tile kernel
     // (keys start from the clear depth, every pixel of the tile is written); anything else that looks at the
-    // targets or the counters first settles it with k_clear.  FRR_CLEAR=eager restores the immediate clear.
+    // targets or the counters first settles it with k_clear.  option clear_eager restores the immediate clear.
     bool part_blocked = false;     // frr_set_partition_layout: contiguous blocks of tile rows instead of interleaved rows
     bool clear_eager = false;
     bool clear_pending = false;    // targets not cleared yet
@@ -73,8 +73,8 @@ struct frr_ctx {
     int debt_rpr = 0;              //   (RasterArgs::rpr of the draw that left the debt)
     uint32_t clear_rgba = 0; float clear_depth = 0.0f;
     int bin_slot = 0;          // Counters::seg_total / ent_cursor slot of the latest draw (alternates)
-    bool bin_atomics = false;  // FRR_BIN=atomics: force the global-atomic binning fallback (tests)
-    size_t bin_cap_init = 0;   // FRR_BIN_CAP: initial bin capacity in entries (tests of the overflow path)
+    bool bin_atomics = false;  // option bin_atomics: force the global-atomic binning fallback (tests)
+    size_t bin_cap_init = 0;   // option bin_capacity: initial bin capacity in entries (tests of the overflow path)
     RasterRec *recs = nullptr; size_t setup_cap = 0;            // [input triangles + fan capacity]
     float *vary = nullptr; size_t vary_cap = 0; // floats
     uint4 *pbox = nullptr; size_t pbox_cap = 0;
@@ -93,9 +93,9 @@ struct frr_ctx {
     uint64_t geom_ntris = 0;
     int rank = 0, world = 1;
     bool count_frags = true;   // exact covered-fragment statistic (disables whole-triangle early-z)
-    int raster_nw = 0;         // FRR_RASTER_NW: force 3 / 4 / 6 / 8 / 16 waves per tile workgroup (dev)
-    int raster_occ = 0;        // FRR_RASTER_OCC: force the 6- or 8-waves-per-SIMD build of the tile kernel (dev)
-    bool raster_sweep = false; // FRR_RASTER=sweep: brute-force tile kernel instead of the span kernel
+    int raster_nw = 0;         // option raster_nw: force 3 / 4 / 6 / 8 / 16 waves per tile workgroup (dev)
+    int raster_occ = 0;        // option raster_occ: force the 6- or 8-waves-per-SIMD build of the tile kernel (dev)
+    bool raster_sweep = false; // option raster_sweep: brute-force tile kernel instead of the span kernel
 #ifdef FRR_DEBUG_COUNTERS
     unsigned long long *dbg_tiles = nullptr; // FRR_DEBUG_TILES: per-tile timeline of the latest tile kernel
 #endif
@@ -140,19 +140,27 @@ template <typename T> int ensure(frr_ctx *c, T *&p, size_t &cap, size_t need)
 hipEvent_t get_event(frr_ctx *c)
 {
     if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;   // (the caller drops the sample)
     return e;
 }
 struct ProfScope {
     frr_ctx *c; int kid; hipEvent_t a = nullptr;
     ProfScope(frr_ctx *c_, int kid_) : c(c_), kid(kid_)
     {
-        if ((c->prof_mask & (1u << kid)) && (c->prof_seen[kid]++ % c->prof_period) == 0) { a = get_event(c); (void)hipEventRecord(a, c->stream); }
+        if ((c->prof_mask & (1u << kid)) && (c->prof_seen[kid]++ % c->prof_period) == 0) {
+            a = get_event(c);
+            if (a && hipEventRecord(a, c->stream) != hipSuccess) { c->ev_pool.push_back(a); a = nullptr; }
+        }
     }
     ~ProfScope()
     {
-        if (a) { hipEvent_t b = get_event(c); (void)hipEventRecord(b, c->stream); c->prof_pending.push_back({kid, a, b}); }
+        // a sample whose events could not be created or recorded is dropped (frr_profile_get then reports fewer launches)
+        if (!a) return;
+        hipEvent_t b = get_event(c);
+        if (b && hipEventRecord(b, c->stream) == hipSuccess) { c->prof_pending.push_back({kid, a, b}); return; }
+        c->ev_pool.push_back(a);
+        if (b) c->ev_pool.push_back(b);
     }
 };
 void prof_collect(frr_ctx *c)
@@ -260,7 +268,7 @@ struct SpanShape { int nw, occ; };
 SpanShape span_shape(const frr_ctx *c, uint32_t grid, uint64_t ntris, int ps_id)
 {
     static const SpanShape all[] = {{16, 4}, {8, 6}, {6, 6}, {4, 8}, {4, 6}, {LIGHT_NW, 6}};
-    if (c->raster_nw || c->raster_occ)                   // FRR_RASTER_NW / FRR_RASTER_OCC (tests, tools)
+    if (c->raster_nw || c->raster_occ)                   // options raster_nw / raster_occ (tests, tools)
         for (const SpanShape &k : all)
             if ((!c->raster_nw || k.nw == c->raster_nw) && (!c->raster_occ || k.occ == c->raster_occ)) return k;
     if (grid <= 256u) return {16, 4};
@@ -336,15 +344,6 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     if (hipSetDevice(device) != hipSuccess) return FRR_ERR_HIP;
     frr_ctx *c = new frr_ctx();
     c->device = device; c->W = width; c->H = height;
-    { const char *e = getenv("FRR_RASTER"); c->raster_sweep = e && strcmp(e, "sweep") == 0; }
-    { const char *e = getenv("FRR_RASTER_NW"); const int v = e ? atoi(e) : 0; c->raster_nw = (v == 3 || v == 4 || v == 6 || v == 8 || v == 16) ? v : 0; }
-    { const char *e = getenv("FRR_RASTER_OCC"); const int v = e ? atoi(e) : 0; c->raster_occ = (v == 4 || v == 6 || v == 8) ? v : 0; }
-    { const char *e = getenv("FRR_BIN_G"); c->bin_g = e ? atoi(e) : 0; }
-    { const char *e = getenv("FRR_FUSE"); c->no_fuse = !(e && strcmp(e, "1") == 0); }
-    { const char *e = getenv("FRR_CLEAR"); c->clear_eager = e && strcmp(e, "eager") == 0; }
-    { const char *e = getenv("FRR_ENT_SLOT"); c->ent_slot_override = e ? (uint32_t)atoi(e) : 0u; }
-    { const char *e = getenv("FRR_BIN"); c->bin_atomics = e && strcmp(e, "atomics") == 0; }
-    { const char *e = getenv("FRR_BIN_CAP"); c->bin_cap_init = e ? (size_t)atoll(e) : 0; }
     if (stream) c->stream = (hipStream_t)stream;
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FRR_ERR_HIP; } c->own_stream = true; }
     const size_t npx = (size_t)width * height;
@@ -395,6 +394,24 @@ void frr_destroy(frr_ctx *c)
 }
 
 static int settle(frr_ctx *c); // deferred frr_clear, below
+
+int frr_set_option(frr_ctx *c, const char *name, int64_t v)
+{
+    if (!c || !name) return FRR_ERR_INVALID;
+    { int rc = settle(c); if (rc != FRR_OK) return rc; }   // nothing half-done under the old setting
+    const std::string n(name);
+    if (n == "raster_sweep") c->raster_sweep = v != 0;
+    else if (n == "raster_nw") { if (v != 0 && v != LIGHT_NW && v != 4 && v != 6 && v != 8 && v != 16) return fail(c, FRR_ERR_INVALID, "raster_nw: 0, 3, 4, 6, 8 or 16"); c->raster_nw = (int)v; }
+    else if (n == "raster_occ") { if (v != 0 && v != 4 && v != 6 && v != 8) return fail(c, FRR_ERR_INVALID, "raster_occ: 0, 4, 6 or 8"); c->raster_occ = (int)v; }
+    else if (n == "bin_chunks") { if (v < 0) return fail(c, FRR_ERR_INVALID, "bin_chunks >= 0"); c->bin_g = (int)std::min<int64_t>(v, BIN_MAX_G); }
+    else if (n == "fuse_geometry_binning") c->no_fuse = v == 0;
+    else if (n == "clear_eager") c->clear_eager = v != 0;
+    else if (n == "tile_slot_records") { if (v < 0 || v > 0x7FFFFFFF) return fail(c, FRR_ERR_INVALID, "tile_slot_records out of range"); c->ent_slot_override = (uint32_t)v; }
+    else if (n == "bin_atomics") c->bin_atomics = v != 0;
+    else if (n == "bin_capacity") { if (v < 0) return fail(c, FRR_ERR_INVALID, "bin_capacity >= 0"); c->bin_cap_init = (size_t)v; }
+    else return fail(c, FRR_ERR_INVALID, "unknown option");
+    return FRR_OK;
+}
 
 int frr_set_partition(frr_ctx *c, int rank, int world)
 {
@@ -909,6 +926,7 @@ int frr_get_stats(frr_ctx *c, frr_stats *out)
     out->frag_nan = h.frag_nan;
     out->draws = h.draws;
     out->overflow = h.overflow;
+#ifdef FRR_DEBUG_COUNTERS
     if (getenv("FRR_DEBUG_PRINT")) {
         fprintf(stderr, "frr dbg:");
         for (int k = 0; k < 24; ++k) {
@@ -918,6 +936,7 @@ int frr_get_stats(frr_ctx *c, frr_stats *out)
         }
         fprintf(stderr, "\n");
     }
+#endif
     return FRR_OK;
 }
 

@@ -291,6 +291,7 @@ public:
     void free_mesh(Mesh &m) { if (m.id >= 0) { check(frr_mesh_free(ctx_, m.id)); m.id = -1; } }
     void set_texture(int slot, const FrameBuffer &fb) { check(frr_texture_upload(ctx_, slot, fb.get_data().data(), fb.width(), fb.height())); }
     void set_uniforms() { check(frr_set_uniforms(ctx_, &uniforms)); }
+    void set_option(const char *name, int64_t value) { check(frr_set_option(ctx_, name, value)); }   // dev / test switches, include/frr.h
     void set_partition(int rank, int world, bool blocked = false)
     {
         check(frr_set_partition(ctx_, rank, world));

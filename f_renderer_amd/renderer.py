@@ -110,6 +110,26 @@ class Mesh:
             self.id = None
 
 
+def _options_from_env():
+    """The test-suite and the tools select code paths with FRR_* environment variables; the library reads none, so they
+    are translated into frr_set_option calls here (every new Renderer)."""
+    import os
+    e, o = os.environ, {}
+    if e.get("FRR_RASTER") == "sweep":
+        o["raster_sweep"] = 1
+    for var, name in (("FRR_RASTER_NW", "raster_nw"), ("FRR_RASTER_OCC", "raster_occ"), ("FRR_BIN_G", "bin_chunks"),
+                      ("FRR_ENT_SLOT", "tile_slot_records"), ("FRR_BIN_CAP", "bin_capacity")):
+        if e.get(var):
+            o[name] = int(e[var])
+    if e.get("FRR_FUSE") == "1":
+        o["fuse_geometry_binning"] = 1
+    if e.get("FRR_CLEAR") == "eager":
+        o["clear_eager"] = 1
+    if e.get("FRR_BIN") == "atomics":
+        o["bin_atomics"] = 1
+    return o
+
+
 class Renderer:
     """Device-resident FrameBuffer (width x height RGBA8) + f32 depth buffer + u32 triangle-id
     buffer, and the two halves of the reference's draw loop (phong.rs:319-381) as batched calls."""
@@ -135,6 +155,12 @@ class Renderer:
         self.uniforms.flat_color[:] = [1.0, 1.0, 1.0, 1.0]
         self._keep = []
         self.last_warning = None
+        for name, value in _options_from_env().items():
+            self.set_option(name, value)
+
+    def set_option(self, name, value):
+        """Development / test switches of the library (include/frr.h: frr_set_option); none changes a result."""
+        self._check(self._lib.frr_set_option(self._ctx, name.encode(), int(value)))
 
     # -- lifetime / errors --
     def close(self):

@@ -190,6 +190,19 @@ int frr_get_stats(frr_ctx *ctx, frr_stats *out);
 /* slot in [0,16): record an event now; elapsed in ms between two recorded slots (syncs on `b`). */
 int frr_event_record(frr_ctx *ctx, int slot);
 int frr_event_elapsed_ms(frr_ctx *ctx, int a, int b, float *ms);
+/* Development and test switches of a ctx (frr_set_option(ctx, name, value); unknown name or bad value: FRR_ERR_INVALID).
+ * None changes a result: every path is held to the same oracle by the tests.  The library itself reads no environment
+ * variable; the Python binding maps FRR_* variables onto these for the test-suite and the tools.
+ *   "raster_sweep"            1: brute-force tile kernel (one triangle per wavefront) instead of the span kernel
+ *   "raster_nw", "raster_occ" waves per tile workgroup (3, 4, 6, 8, 16) / waves per SIMD its registers are budgeted for
+ *                             (4, 6, 8); 0 = chosen per launch
+ *   "bin_chunks"              number of chunk workgroups of the segmented binning (0 = by mesh size)
+ *   "bin_atomics"             1: global-atomic CSR binning (the path for windows of more than 36,864 tiles)
+ *   "bin_capacity"            initial capacity of the (triangle, tile) lists in records (overflow / re-issue tests)
+ *   "tile_slot_records"       records per tile slot of the near-first copy (tests of its overflow arena)
+ *   "fuse_geometry_binning"   1: frr_draw sets up and bins in one launch (k_geom_bin; measured slower, default 0)
+ *   "clear_eager"             1: frr_clear runs its own kernel at once instead of riding on the next full-window draw */
+int frr_set_option(frr_ctx *ctx, const char *name, int64_t value);
 /* per-kernel accumulated device time (ms) and launch count since frr_profile_reset.  `mask`:
  * 0 = off, -1 = every kernel, else OR of (1 << index) with index in the order k_clear,
  * k_geom, k_geom_scan, k_geom_bin, k_bin_count, k_tile_scan, k_bin_fill, k_raster,

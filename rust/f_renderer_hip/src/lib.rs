@@ -53,6 +53,7 @@ pub mod ffi {
         pub fn frr_create(device: c_int, width: u32, height: u32, stream: *mut c_void, out: *mut *mut frr_ctx) -> c_int;
         pub fn frr_destroy(ctx: *mut frr_ctx);
         pub fn frr_last_error(ctx: *const frr_ctx) -> *const c_char;
+        pub fn frr_set_option(ctx: *mut frr_ctx, name: *const c_char, value: i64) -> c_int;
         pub fn frr_set_partition(ctx: *mut frr_ctx, rank: c_int, world: c_int) -> c_int;
         pub fn frr_set_partition_layout(ctx: *mut frr_ctx, blocked: c_int) -> c_int;
         pub fn frr_owned_band_count(ctx: *const frr_ctx, y0: i32, y1: i32) -> c_int;
@@ -211,6 +212,11 @@ impl Renderer {
     }
 
     // ---- multi-GPU: one process per GPU, screen tile rows split over the ranks (renderer.rs:270-271's sub-window) ----
+    /// Development / test switches (`include/frr.h`: `frr_set_option`); none changes a result.
+    pub fn set_option(&mut self, name: &str, value: i64) -> Result<(), Error> {
+        let n = std::ffi::CString::new(name).map_err(|_| Error { code: -1, message: "option name contains NUL".into() })?;
+        self.check(unsafe { ffi::frr_set_option(self.ctx, n.as_ptr(), value) })
+    }
     pub fn set_partition(&mut self, rank: i32, world: i32, blocked: bool) -> Result<(), Error> {
         self.check(unsafe { ffi::frr_set_partition(self.ctx, rank, world) })?;
         self.check(unsafe { ffi::frr_set_partition_layout(self.ctx, blocked as c_int) })

@@ -391,3 +391,27 @@ def test_nan_depth_fragments_shaded_and_many_tiles(oracle):
     np.testing.assert_array_equal(t, f.tri_id)
     assert_depth_equal(d, f.depth)
     np.testing.assert_array_equal(c, f.color)
+
+
+def test_set_option_rejects_unknown_names_and_values(oracle):
+    """frr_set_option (include/frr.h): the library's development switches; it reads no environment variable itself (the
+    Python binding translates FRR_* for the tests).  Unknown names and impossible values are FRR_ERR_INVALID, and a ctx
+    keeps working afterwards."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H = 96, 64
+    r = fr.Renderer(W, H)
+    for name, value in (("no_such_switch", 1), ("raster_nw", 5), ("raster_occ", 7), ("bin_chunks", -1)):
+        with pytest.raises(fr.FrrError) as e:
+            r.set_option(name, value)
+        assert e.value.code == fr.FRR_ERR_INVALID
+    tris = scenes.random_clip_triangles(2000, W, H, seed=3)
+    f = _oracle_depth(oracle, tris, W, H)
+    for name, value in ((None, 0), ("raster_nw", 8), ("raster_sweep", 1), ("bin_atomics", 1), ("clear_eager", 1)):
+        if name:
+            r.set_option(name, value)
+        r.clear()
+        r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
+        _, d, t = r.readback()
+        np.testing.assert_array_equal(t, f.tri_id)
+        assert_depth_equal(d, f.depth)
