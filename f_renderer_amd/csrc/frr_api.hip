@@ -14,9 +14,9 @@ using namespace frr;
 
 namespace {
 
-enum KernelId { KID_CLEAR, KID_GEOM, KID_GEOM_SCAN, KID_GEOM_BIN, KID_BIN_COUNT,
+enum KernelId { KID_CLEAR, KID_GEOM, KID_GEOM_SCAN, KID_BIN_COUNT,
                 KID_TILE_SCAN, KID_BIN_FILL, KID_RASTER, KID_BIN_SEG, KID_COUNT };
-const char *const kKernelNames[KID_COUNT] = {"k_clear", "k_geom", "k_geom_scan", "k_geom_bin",
+const char *const kKernelNames[KID_COUNT] = {"k_clear", "k_geom", "k_geom_scan",
                                              "k_bin_count", "k_tile_scan", "k_bin_fill",
                                              "k_raster", "k_bin_seg"};
 
@@ -54,11 +54,6 @@ struct frr_ctx {
     uint32_t geom_fan_cap = 0; // fan capacity the latest draw was launched with
     uint32_t geom_nblocks = 0;
     bool scan_pending = false; // the latest draw's block sums are not scanned yet (geom_scan: by the binning launch, or k_geom_scan)
-    bool geom_deferred = false; // frr_draw: the geometry kernel is not launched yet (frr_raster may fuse it with the binning)
-    GeomArgs geom_args;         //   ... its arguments
-    bool no_fuse = true;        // option fuse_geometry_binning = 1 fuses frr_draw's geometry and binning into one launch (k_geom_bin): parity-tested, but measured
-                                // 4-7 % slower per frame than the two launches (1024-thread workgroups halve the geometry phase's occupancy)
-    bool fuse_attr_set[4] = {false, false, false, false};
     size_t fan_hint = 0;       // fan capacity asked for by a draw that overflowed
     int bin_g = 0;             // option bin_chunks: override the number of binning chunks (dev)
     uint32_t ent_slot_override = 0; // option tile_slot_records: per-tile slot of bins2 in records (tests of the overflow arena)
@@ -229,7 +224,7 @@ template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks
     hipLaunchKernelGGL(k_geom_single<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni);
 }
 
-// the geometry kernel proper (unfused), for the VS of the mesh
+// the geometry kernel for the VS of the mesh
 void launch_geometry_vs(frr_ctx *c, GeomArgs &g, uint32_t nblocks, int vs)
 {
     switch (vs) {
@@ -239,18 +234,9 @@ void launch_geometry_vs(frr_ctx *c, GeomArgs &g, uint32_t nblocks, int vs)
     case FRR_VS_GOURAUD: launch_geometry<FRR_VS_GOURAUD>(c, g, nblocks); break;
     }
 }
-// frr_draw defers its geometry launch so that frr_raster can fuse it with the binning; whoever cannot fuse launches it here
-void flush_deferred_geometry(frr_ctx *c)
-{
-    if (!c->geom_deferred) return;
-    c->geom_deferred = false;
-    launch_geometry_vs(c, c->geom_args, c->geom_nblocks, c->geom_vs);
-}
-
 // the latest draw's block sums -> prefix (+ n_emit, the fan-capacity flag), if no binning launch has done it
 int scan_now(frr_ctx *c)
 {
-    flush_deferred_geometry(c);
     if (!c->scan_pending) return FRR_OK;
     { ProfScope p(c, KID_GEOM_SCAN); hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, c->stream, c->block_sums, c->geom_nblocks, c->cnt, c->geom_slot, c->geom_fan_cap); }
     HIP_TRY(c, hipGetLastError());
@@ -404,7 +390,6 @@ int frr_set_option(frr_ctx *c, const char *name, int64_t v)
     else if (n == "raster_nw") { if (v != 0 && v != LIGHT_NW && v != 4 && v != 6 && v != 8 && v != 16) return fail(c, FRR_ERR_INVALID, "raster_nw: 0, 3, 4, 6, 8 or 16"); c->raster_nw = (int)v; }
     else if (n == "raster_occ") { if (v != 0 && v != 4 && v != 6 && v != 8) return fail(c, FRR_ERR_INVALID, "raster_occ: 0, 4, 6 or 8"); c->raster_occ = (int)v; }
     else if (n == "bin_chunks") { if (v < 0) return fail(c, FRR_ERR_INVALID, "bin_chunks >= 0"); c->bin_g = (int)std::min<int64_t>(v, BIN_MAX_G); }
-    else if (n == "fuse_geometry_binning") c->no_fuse = v == 0;
     else if (n == "clear_eager") c->clear_eager = v != 0;
     else if (n == "tile_slot_records") { if (v < 0 || v > 0x7FFFFFFF) return fail(c, FRR_ERR_INVALID, "tile_slot_records out of range"); c->ent_slot_override = (uint32_t)v; }
     else if (n == "bin_atomics") c->bin_atomics = v != 0;
@@ -604,7 +589,7 @@ int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
     return FRR_OK;
 }
 
-static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filter, int32_t fy0, int32_t fy1, bool defer = false)
+static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filter, int32_t fy0, int32_t fy1)
 {
     if (!c || mesh < 0 || mesh >= (int)c->meshes.size() || !c->meshes[mesh].used) return fail(c, FRR_ERR_INVALID, "bad mesh id");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -654,10 +639,6 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     c->geom_vs = m.vs; c->geom_ntris = nt;
     if (nt == 0) {
         hipLaunchKernelGGL(k_geom_empty, dim3(1), dim3(64), 0, c->stream, g);
-    } else if (defer) {
-        c->geom_args = g;          // frr_draw: frr_raster launches it, fused with the binning when it can
-        c->geom_deferred = true;
-        c->scan_pending = true;
     } else {
         launch_geometry_vs(c, g, nblocks, m.vs);
         c->scan_pending = true;
@@ -758,20 +739,6 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
             HIP_TRY(c, hipFuncSetAttribute((const void *)k_bin_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
             c->lds_attr_set = true;
         }
-        // frr_draw's geometry is still to be launched: fuse it with the binning when the geometry phase's staging fits
-        // beside the tile histogram and a workgroup's chunk is at most GB_MAX_ROUNDS rounds
-        uint32_t fchunk = 0;
-        bool fuse = false;
-        if (c->geom_deferred && !c->no_fuse) {
-            const uint32_t gmax = std::min<uint32_t>((uint32_t)BIN_MAX_G, sh.nw == 3 ? 256u : (uint32_t)sh.nw * 64u);
-            fchunk = (uint32_t)(((c->geom_ntris + gmax - 1) / gmax + BIN_WG - 1) / BIN_WG * BIN_WG);
-            const size_t geom_lds = c->geom_vs == FRR_VS_CLIP ? (size_t)GeomBinLds<FRR_VS_CLIP>::END :
-                                    c->geom_vs == FRR_VS_CLIP_COLOR ? (size_t)GeomBinLds<FRR_VS_CLIP_COLOR>::END :
-                                    c->geom_vs == FRR_VS_PHONG ? (size_t)GeomBinLds<FRR_VS_PHONG>::END : (size_t)GeomBinLds<FRR_VS_GOURAUD>::END;
-            fuse = fchunk <= (uint32_t)GB_MAX_ROUNDS * BIN_WG && hist_bytes + geom_lds <= kLdsBudget;
-        }
-        if (fuse) G = (uint32_t)((c->geom_ntris + fchunk - 1) / fchunk);
-        else flush_deferred_geometry(c);
         c->bin_slot ^= 1;
         a.seg = c->bin_matrix; a.nseg = G; a.slot = c->bin_slot;
         // near-first copies (bins2): a fixed slot per tile, 8x the mean tile load, + an overflow arena of bin_cap records
@@ -782,28 +749,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xBFFFFFFFu);
         if ((rc = ensure(c, c->bins2, c->bin2_cap, (size_t)ltiles * S + a.bin_cap)) != FRR_OK) return rc;
         a.bins2 = c->bins2;
-        if (fuse) {
-            // geometry + binning in one launch; its last workgroup scans the block sums
-            ProfScope p(c, KID_GEOM_BIN);
-            c->geom_deferred = false;
-            GeomArgs &g = c->geom_args;
-            auto go = [&](auto vs_tag) {
-                constexpr int VSV = decltype(vs_tag)::value;
-                const size_t flds = hist_bytes + std::max<size_t>((size_t)GeomBinLds<VSV>::END, (size_t)stage_cap * 16);
-                if (!c->fuse_attr_set[VSV]) {
-                    (void)hipFuncSetAttribute((const void *)k_geom_bin<VSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-                    c->fuse_attr_set[VSV] = true;
-                }
-                hipLaunchKernelGGL(k_geom_bin<VSV>, dim3(G), dim3(BIN_WG), flds, c->stream, g, c->duni, a, ltiles, c->bin_matrix, a.slot, stage_cap,
-                                   c->geom_nblocks, fchunk);
-            };
-            switch (c->geom_vs) {
-            case FRR_VS_CLIP: go(std::integral_constant<int, FRR_VS_CLIP>{}); break;
-            case FRR_VS_CLIP_COLOR: go(std::integral_constant<int, FRR_VS_CLIP_COLOR>{}); break;
-            case FRR_VS_PHONG: go(std::integral_constant<int, FRR_VS_PHONG>{}); break;
-            default: go(std::integral_constant<int, FRR_VS_GOURAUD>{}); break;
-            }
-        } else {
+        {
             ProfScope p(c, KID_BIN_SEG);
             hipLaunchKernelGGL(k_bin_seg, dim3(G + do_scan), dim3(BIN_WG), lds, c->stream, a, ltiles, c->bin_matrix, a.slot, stage_cap,
                                c->geom_slot, c->geom_fan_cap, c->block_sums, c->geom_nblocks, do_scan);
@@ -811,7 +757,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         c->scan_pending = false;
     } else {
         // fallback for frames with more tiles than fit LDS counters: global atomics
-        if ((rc = scan_now(c)) != FRR_OK) return rc;   // (also launches a deferred geometry kernel)
+        if ((rc = scan_now(c)) != FRR_OK) return rc;
         const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((c->geom_ntris + c->geom_fan_cap + 255) / 256, 2048);
         { ProfScope p(c, KID_BIN_COUNT); hipLaunchKernelGGL(k_bin<false>, dim3(bin_grid), dim3(256), 0, c->stream, a, c->geom_slot, c->geom_fan_cap); }
         { ProfScope p(c, KID_TILE_SCAN); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, a, ntiles); }
@@ -842,11 +788,9 @@ int frr_draw(frr_ctx *c, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0
     // frr_draw knows the raster window, so a partitioned ctx can skip the setup records of triangles
     // that touch none of its tile rows (frr_geometry alone cannot: the window comes later)
     const bool filter = c && c->world > 1 && y0 <= y1;
-    int rc = geometry_impl(c, mesh, nullptr, filter, y0, y1, /*defer=*/true);
+    int rc = geometry_impl(c, mesh, nullptr, filter, y0, y1);
     if (rc != FRR_OK) return rc;
-    rc = frr_raster(c, ps_id, x0, x1, y0, y1);
-    flush_deferred_geometry(c);   // (an frr_raster that returned early or failed has not launched it)
-    return rc;
+    return frr_raster(c, ps_id, x0, x1, y0, y1);
 }
 
 int frr_sync(frr_ctx *c)

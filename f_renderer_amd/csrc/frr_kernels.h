@@ -46,16 +46,20 @@ __global__ void k_clear_tail(uint32_t *color, uint32_t *depth, uint32_t *ids, ui
 }
 
 // ---- block-level helpers -------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+// wave64 inclusive prefix sum on the DPP network (row_shr within 16-lane rows, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
     return v;
 }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) { return wave_incl_scan_dpp(v); }
 // exclusive scan of one value per thread over a 256-thread block; returns block total via `total`
 __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t *s_w /*[4]*/, uint32_t &total)
 {
@@ -90,18 +94,24 @@ __device__ __forceinline__ TileRange tiles_of_pbox(const RasterArgs &a, const ui
     return t;
 }
 
-// where a record goes: the first stage_cap records of the workgroup's region are collected in LDS in their final order
-// and leave as coalesced full-line stores (a scattered 16-B store is a partial-line write: WRITE_SIZE showed 2.3x the
-// bytes); what does not fit goes straight to memory
-struct BinPut {
+// Where a record goes.  Positions are RELATIVE to the workgroup's region of `bins` (the LDS cursors count from 0): the
+// first stage_cap records of the region are collected in LDS in their final order and leave as coalesced full-line
+// stores (a scattered 16-B store is a partial-line write: WRITE_SIZE showed 2.3x the bytes).  PutStaged: the whole
+// region fits the staging, so nobody needs to know where the region starts until the walk is over (the global atomic
+// that reserves it is in flight meanwhile); PutMixed: what does not fit goes straight to memory.  pos = ~0u: nothing.
+struct PutNone { __device__ __forceinline__ void operator()(uint32_t, const uint4 &) const {} };
+struct PutStaged {
+    uint4 *s_stage;
+    __device__ __forceinline__ void operator()(uint32_t pos, const uint4 &ent) const { if (pos != ~0u) s_stage[pos] = ent; }
+};
+struct PutMixed {
     uint4 *s_stage, *bins;
     uint32_t region, stage_cap, bin_cap;
-    __device__ __forceinline__ void operator()(uint32_t pos, const uint4 &ent) const // pos = ~0u: nothing
+    __device__ __forceinline__ void operator()(uint32_t pos, const uint4 &ent) const
     {
-        const uint32_t local = pos - region;
         if (pos != ~0u) {
-            if (local < stage_cap) s_stage[local] = ent;
-            else if (pos < bin_cap) bins[pos] = ent;
+            if (pos < stage_cap) s_stage[pos] = ent;
+            else if (region + pos < bin_cap) bins[region + pos] = ent;   // (region == bin_cap: the frame overflowed, nothing is stored)
         }
     }
 };
@@ -109,8 +119,8 @@ struct BinPut {
 // One binning record per lane (pb = the lane's pbox entry, all zero = nothing; the lanes of a wave hold the consecutive
 // slots base .. base+63): count it (SCATTER = false) or place it (true) in every owned tile its clamped bbox touches.
 // Called by whole waves: large footprints are spread over the lanes.
-template <bool SCATTER>
-__device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, const uint4 pb, uint32_t base, int lane, const BinPut &put)
+template <bool SCATTER, class PUT>
+__device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, const uint4 pb, uint32_t base, int lane, const PUT &put)
 {
     const uint32_t i = base + (uint32_t)lane;
     const TileRange t = tiles_of_pbox(a, pb);
@@ -190,9 +200,9 @@ __device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, c
 }
 
 // the slots [lo, hi) of `pbox`, by the waves of a BIN_WG-thread workgroup
-template <bool SCATTER>
+template <bool SCATTER, class PUT>
 __device__ __forceinline__ void bin_walk(const RasterArgs &a, uint32_t *s_hist, const uint4 *__restrict__ pbox, uint32_t lo, uint32_t hi,
-                                         int lane, uint32_t wave, const BinPut &put)
+                                         int lane, uint32_t wave, const PUT &put)
 {
     constexpr int PF = 4; // bboxes of PF rounds are fetched up front: the loop is latency-bound otherwise
     for (uint32_t base0 = lo + wave * 64u; base0 < hi; base0 += PF * BIN_WG) {
@@ -211,40 +221,42 @@ __device__ __forceinline__ void bin_walk(const RasterArgs &a, uint32_t *s_hist, 
     }
 }
 
-// Exclusive scan of the workgroup's tile histogram in place, ONE global atomic to reserve its region of `bins`, and its
-// row of the segment table; returns the region's first record (bin_cap when the frame overflowed) and its size.
-__device__ __forceinline__ void bin_reserve_publish(const RasterArgs &a, uint32_t *s_hist, uint32_t ntiles, uint32_t *__restrict__ row, int slot,
-                                                    uint32_t *s_w /*[BIN_WG/64]*/, uint32_t *s_base, int lane, uint32_t wave,
-                                                    uint32_t &base_out, uint32_t &total_out)
+// Exclusive scan of the workgroup's tile histogram in place (counts -> where each tile's records start, relative to the
+// workgroup's region); returns the region's size.  4096 tiles per step: every thread takes FOUR CONSECUTIVE counters as
+// one 16-byte LDS access (a thread owning a longer slice of consecutive tiles reads LDS at a stride of the slice length:
+// with 16 tiles per thread, the 4096^2 frame, that was a 32-way bank conflict and 14 us per workgroup); the wave totals
+// are combined by a second DPP scan in every wave.  The histogram is padded with zeros to a multiple of four counters.
+// sw: two alternating arrays of wave totals, so that one barrier per step is enough.
+__device__ __forceinline__ uint32_t bin_scan_relative(uint32_t *s_hist, uint32_t ntiles, uint32_t (*sw)[BIN_WG / 64], int lane, uint32_t wave)
 {
-    // thread i owns the slice [i*per, (i+1)*per)
-    const uint32_t per = (ntiles + BIN_WG - 1) / BIN_WG;
-    const uint32_t t0 = min(ntiles, threadIdx.x * per), t1 = min(ntiles, t0 + per);
-    uint32_t sum = 0;
-    for (uint32_t t = t0; t < t1; ++t) sum += s_hist[t];
-    const uint32_t inc = wave_incl_scan(sum);
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < BIN_WG / 64; ++k) { const uint32_t x = s_w[k]; if (k < (int)wave) wbase += x; total += x; }
-    if (threadIdx.x == 0) {
-        const unsigned long long b64 = atomicAdd(&a.cnt->seg_total[slot], (unsigned long long)total);
-        uint32_t base = (uint32_t)b64;
-        if (b64 + total > (unsigned long long)a.bin_cap) { atomicOr(&a.cnt->overflow, 2u); base = a.bin_cap; } // frame flagged invalid; nothing of this chunk is stored
-        *s_base = base;
+    static_assert(BIN_WG / 64 <= 16, "the wave totals are scanned inside one 16-lane DPP row");
+    uint32_t carry = 0;
+    int it = 0;
+    for (uint32_t base = 0; base < ntiles; base += 4 * BIN_WG, it ^= 1) {
+        const uint32_t i = base + 4u * threadIdx.x;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i < ntiles) v = *reinterpret_cast<const uint4 *>(s_hist + i);
+        const uint32_t s = (v.x + v.y) + (v.z + v.w);
+        const uint32_t inc = wave_incl_scan_dpp(s);
+        if (lane == 63) sw[it][wave] = inc;
+        __syncthreads();
+        const uint32_t wt = wave_incl_scan_dpp(lane < BIN_WG / 64 ? sw[it][lane] : 0u);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wt, BIN_WG / 64 - 1);
+        const uint32_t wbase = wave ? (uint32_t)__builtin_amdgcn_readlane((int)wt, (int)wave - 1) : 0u;
+        if (i < ntiles) {
+            const uint32_t e0 = carry + wbase + inc - s;
+            *reinterpret_cast<uint4 *>(s_hist + i) = make_uint4(e0, e0 + v.x, e0 + v.x + v.y, e0 + v.x + v.y + v.z);
+        }
+        carry += tot;
     }
-    __syncthreads();
-    const uint32_t base = *s_base;
-    {
-        uint32_t run = base + (wbase + inc - sum);
-        for (uint32_t t = t0; t < t1; ++t) { const uint32_t x = s_hist[t]; s_hist[t] = min(run, a.bin_cap); run += x; }
-    }
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) row[t] = s_hist[t];
-    if (threadIdx.x == 0) row[ntiles] = (uint32_t)min((unsigned long long)base + total, (unsigned long long)a.bin_cap);
-    __syncthreads(); // rows are read from LDS above before the cursors start moving
-    base_out = base; total_out = total;
+    __syncthreads(); // the cursors start moving
+    return carry;
+}
+// the workgroup's region of `bins`: ONE global atomic (by one thread; bin_cap when the frame overflowed, which flags it)
+__device__ __forceinline__ uint32_t bin_region_of(const RasterArgs &a, unsigned long long before, uint32_t total)
+{
+    if (before + total > (unsigned long long)a.bin_cap) { atomicOr(&a.cnt->overflow, 2u); return a.bin_cap; }
+    return (uint32_t)before;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -600,182 +612,6 @@ __global__ __launch_bounds__(1024) void k_geom_scan(uint32_t *sums, uint32_t nbl
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1+K2 fused: geometry AND binning of one frr_draw in ONE launch (frr_draw knows the raster window, so the tiles
-// a triangle touches are known the moment it is set up).  Workgroup g of <= 256 (1024 threads, one per CU) owns a chunk
-// of the input triangles and
-//   1. sets them up in rounds of 1024 -- four 256-triangle geometry blocks side by side, the same code and the same
-//      per-block bookkeeping as k_geom_single -- counting every triangle it has just set up (fans included) into its
-//      LDS tile histogram;
-//   2. scans the histogram, reserves its region of `bins` with ONE global atomic and publishes its row of the segment
-//      table (as k_bin_seg);
-//   3. walks its own slots and the fan ranges it handed out again (the 16-byte records are L2-hot: this CU wrote them),
-//      scatters into an LDS staging copy of its region and writes it out coalesced;
-//   4. stores its block sums past L2 (agent scope) and counts itself in: the LAST workgroup to finish scans all block
-//      sums (geom_scan) -- the hand-off is placement independent (MI355X guide, inter-workgroup visibility: write-through
-//      stores, every storing wave's vmcnt(0), workgroup barrier, one agent-scope atomic; the reader learns it is last
-//      from the value its add returned and reads with agent-scope loads).
-// Against k_geom_single + k_bin_seg this saves the 16 MB read-back of the binning records from HBM, a launch boundary
-// and the start-up of a second latency-bound kernel.
-// ---------------------------------------------------------------------------------------------
-constexpr int GB_GROUPS = BIN_WG / GEOM_BLOCK; // geometry blocks per round
-constexpr int GB_MAX_ROUNDS = 16;               // rounds per workgroup: chunks up to 16,384 triangles (4.2 M per mesh)
-
-template <int VS> struct GeomBinLds { // the geometry phase's part of the dynamic LDS (the binning phase's staging aliases it)
-    static constexpr int KS = VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1;
-    static constexpr int NWV = BIN_WG / 64;
-    static constexpr int STAGE = 0;                                        // uint4[NWV][256]: 64 records per wave, pieces swizzled
-    static constexpr int CXY = STAGE + NWV * 4096;                         // float[NWV][21][2]
-    static constexpr int CKEY = CXY + NWV * CLIP_MAXV * 8;                 // int32[NWV][21]
-    static constexpr int CV = CKEY + ((NWV * CLIP_MAXV * 4 + 15) & ~15);   // float[NWV][21][7 + KS]
-    static constexpr int CL = CV + ((NWV * CLIP_MAXV * (7 + KS) * 4 + 15) & ~15); // u32[GB_GROUPS][256]
-    static constexpr int END = CL + GB_GROUPS * GEOM_BLOCK * 4;
-};
-
-template <int VS>
-__global__ __launch_bounds__(BIN_WG) void k_geom_bin(GeomArgs g, DevUniforms u, RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg,
-                                                    int bslot, uint32_t stage_cap, uint32_t nblocks, uint32_t chunk)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[]; // [ntiles], then the union {geometry staging | binning staging}
-    using L = GeomBinLds<VS>;
-    constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K, KS = L::KS;
-    unsigned char *const s_u = reinterpret_cast<unsigned char *>(s_hist + ((ntiles + 3u) & ~3u));
-    uint4 *const s_rstage = reinterpret_cast<uint4 *>(s_u + L::STAGE);
-    float (*const s_cxy)[CLIP_MAXV][2] = reinterpret_cast<float (*)[CLIP_MAXV][2]>(s_u + L::CXY);
-    int32_t (*const s_ckey)[CLIP_MAXV] = reinterpret_cast<int32_t (*)[CLIP_MAXV]>(s_u + L::CKEY);
-    float (*const s_cv)[CLIP_MAXV][7 + KS] = reinterpret_cast<float (*)[CLIP_MAXV][7 + KS]>(s_u + L::CV);
-    uint32_t *const s_cl = reinterpret_cast<uint32_t *>(s_u + L::CL);
-    uint4 *const s_bstage = reinterpret_cast<uint4 *>(s_u);
-    __shared__ uint32_t s_w[BIN_WG / 64], s_wf[BIN_WG / 64];
-    __shared__ uint32_t s_ncl[GB_GROUPS], s_fbase[GB_GROUPS];
-    __shared__ uint2 s_fanr[GB_MAX_ROUNDS * GB_GROUPS];   // fan ranges (first slot, count) handed out by this workgroup
-    __shared__ uint32_t s_base, s_last;
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = (int)(wave >> 2), wg = (int)(wave & 3u), tin = threadIdx.x & (GEOM_BLOCK - 1);
-    const uint32_t gi = blockIdx.x, G = gridDim.x;
-    for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) s_hist[t] = 0u;
-    if (threadIdx.x < GB_GROUPS) s_ncl[threadIdx.x] = 0u;
-    if (gi == 0 && threadIdx.x == 0) { geom_bookkeeping(g); bin_bookkeeping(g.cnt, bslot); }
-    __syncthreads();
-    const uint32_t lo = min(g.ntris, gi * chunk), hi = min(g.ntris, lo + chunk);
-    const uint32_t rounds = (hi - lo + BIN_WG - 1) / BIN_WG;
-    BinPut put{s_bstage, a.bins, 0u, stage_cap, a.bin_cap};
-    // exclusive scan of one value per thread within each 256-thread group (four waves); total of the group
-    auto group_scan = [&](uint32_t v, uint32_t *sw, uint32_t &total) {
-        const uint32_t inc = wave_incl_scan(v);
-        if (lane == 63) sw[wave] = inc;
-        __syncthreads();
-        const uint32_t w0 = sw[grp * 4], w1 = sw[grp * 4 + 1], w2 = sw[grp * 4 + 2], w3 = sw[grp * 4 + 3];
-        total = w0 + w1 + w2 + w3;
-        return (wg > 0 ? w0 : 0u) + (wg > 1 ? w1 : 0u) + (wg > 2 ? w2 : 0u) + inc - v;
-    };
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t t = lo + r * BIN_WG + threadIdx.x;
-        const uint32_t blk = (lo + r * BIN_WG) / GEOM_BLOCK + (uint32_t)grp;  // this group's geometry block
-        float pos[3][4];
-        float ctx[3][KS];
-        uint32_t n = 0;
-        bool clipped = false;
-        if (t < hi) {
-            const float *in = g.in + (size_t)t * (3 * NF);
-#pragma unroll
-            for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
-            n = classify(pos, clipped);
-        }
-        uint32_t total, ftotal;
-        const uint32_t eoff = group_scan(n, s_w, total);
-        const uint32_t foff = group_scan(clipped ? n : 0u, s_wf, ftotal);
-        if (tin == 0) {
-            if (blk < nblocks) __hip_atomic_store(&g.block_sums[blk], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t fb = ftotal ? atomicAdd(&g.cnt->fan_cursor[g.fslot], ftotal) : 0u;
-            s_fbase[grp] = fb;
-            s_fanr[r * GB_GROUPS + grp] = make_uint2(fb, ftotal);
-        }
-        if (t < hi) g.tinfo[t] = n | (eoff << FAN_BITS);
-        __syncthreads();
-        const uint32_t fbase = s_fbase[grp];
-        const bool fans_ok = fbase + ftotal <= g.fan_cap;
-        if (clipped) {
-            g.fanbase[t] = fbase + foff;
-            if (fans_ok) s_cl[grp * GEOM_BLOCK + atomicAdd(&s_ncl[grp], 1u)] = (uint32_t)tin | (foff << 8);
-        }
-        ScreenVtx s0 = {}, s1 = {}, s2 = {};
-        bool emit = false;
-        if (n == 1u && !clipped) {
-            const float fw = (float)g.width, fh = (float)g.height;
-            s0 = to_screen(pos[0], fw, fh); s1 = to_screen(pos[1], fw, fh); s2 = to_screen(pos[2], fw, fh);
-            emit = tri_rows_owned(g, s0.iy, s1.iy, s2.iy);
-        }
-        uint4 my_pbox = make_uint4(0u, 0u, 0u, 0u);
-        if (emit) {
-            const SetupOut so = setup_unclipped(pos, s0, s1, s2);
-            my_pbox = so.pbox;
-            // the 64 records of a wave leave as four coalesced 1-KB stores, staged through LDS: record rk, 16-byte piece j
-            // sits at rk*4 + (j ^ ((rk >> 1) & 3)) -- conflict-free for the b128 writes and the reads alike
-            const unsigned long long am = __ballot(true);
-            const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-            const int np = __popcll(am);
-            const uint32_t t0 = __builtin_amdgcn_readfirstlane(t);
-            if (__ballot(t == t0 + (uint32_t)rk) == am) {
-                uint4 *st = s_rstage + wave * 256u;
-                const int sw = (rk >> 1) & 3;
-                st[rk * 4 + (0 ^ sw)] = so.q0; st[rk * 4 + (1 ^ sw)] = so.q1; st[rk * 4 + (2 ^ sw)] = so.q2; st[rk * 4 + (3 ^ sw)] = so.q3;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                uint4 *dst = reinterpret_cast<uint4 *>(g.recs + t0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const int c = rk + j * np, rr = c >> 2; dst[c] = st[rr * 4 + ((c & 3) ^ ((rr >> 1) & 3))]; }
-            } else {
-                uint4 *dst = reinterpret_cast<uint4 *>(g.recs + t);
-                dst[0] = so.q0; dst[1] = so.q1; dst[2] = so.q2; dst[3] = so.q3;
-            }
-            if constexpr (K > 0) {
-                float *o = g.vary + (size_t)t * (3 * K);
-#pragma unroll
-                for (int sl = 0; sl < 3; ++sl)
-#pragma unroll
-                    for (int k = 0; k < K; ++k) o[sl * K + k] = so.d0 == sl ? ctx[0][k] : (so.d1 == sl ? ctx[1][k] : ctx[2][k]);
-            }
-        }
-        if (t < hi) g.pbox[t] = my_pbox;
-        bin_one<false>(a, s_hist, my_pbox, t - (uint32_t)lane, lane, put);    // every wave, every lane (empty boxes count nothing)
-        __syncthreads();
-        const uint32_t ncl = s_ncl[grp];
-        for (uint32_t e = (uint32_t)wg; e < ncl; e += 4u) {                   // the block's clipped inputs, one wave per triangle
-            const uint32_t en = s_cl[grp * GEOM_BLOCK + e];
-            const uint32_t fb = fbase + (en >> 8);
-            const uint4 pbf = clip_triangle_wave<VS>(g, u, blk * GEOM_BLOCK + (en & 255u), fb, lane, s_cxy[wave], s_ckey[wave], s_cv[wave]);
-            bin_one<false>(a, s_hist, pbf, g.ntris + fb, lane, put);
-        }
-        __syncthreads();
-        if (tin == 0) s_ncl[grp] = 0u;   // (ordered before the next round's use by the barriers of its scans)
-    }
-    __syncthreads();
-    uint32_t base, total;
-    bin_reserve_publish(a, s_hist, ntiles, seg + (size_t)gi * (ntiles + 1), bslot, s_w, &s_base, lane, wave, base, total);
-    put.region = base;
-    bin_walk<true>(a, s_hist, g.pbox, lo, hi, lane, wave, put);
-    for (uint32_t k = 0; k < rounds * GB_GROUPS; ++k) {
-        const uint2 fr = s_fanr[k];
-        if (fr.y && fr.x + fr.y <= g.fan_cap) bin_walk<true>(a, s_hist, g.pbox, g.ntris + fr.x, g.ntris + fr.x + fr.y, lane, wave, put);
-    }
-    __syncthreads();
-    const uint32_t nstaged = min(total, stage_cap);
-    for (uint32_t j = threadIdx.x; j < nstaged; j += BIN_WG)
-        if (base + j < a.bin_cap) a.bins[base + j] = s_bstage[j];
-    // count this workgroup in; the last one scans the block sums of the whole draw
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&g.cnt->done_ctr, 1u) == G - 1u ? 1u : 0u;
-    __syncthreads();
-    if (s_last) {
-        if (threadIdx.x == 0) g.cnt->done_ctr = 0u;
-        geom_scan<true>(g.block_sums, nblocks, g.cnt, g.fslot, g.fan_cap);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // K2 binning.  A setup triangle goes into every OWNED 32x32 tile its clamped bbox
 // (renderer.rs:285-298) touches.  Small footprints are handled per lane; a triangle touching
 // more than BIN_COOP tiles is spread over the 64 lanes of its wave.
@@ -882,10 +718,10 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     if (do_scan && blockIdx.x == gridDim.x - 1) { geom_scan(block_sums, nblocks, a.cnt, fslot, fan_cap); return; }
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[]; // [ntiles], then the staging records
     uint4 *s_stage = reinterpret_cast<uint4 *>(s_hist + ((ntiles + 3u) & ~3u));
-    __shared__ uint32_t s_w[BIN_WG / 64];
+    __shared__ uint32_t s_w[2][BIN_WG / 64];
     __shared__ uint32_t s_base;
     const uint32_t g = blockIdx.x, G = gridDim.x - (uint32_t)do_scan;
-    for (uint32_t t = threadIdx.x; t < ntiles; t += BIN_WG) s_hist[t] = 0u;
+    for (uint32_t t = threadIdx.x; t < ((ntiles + 3u) & ~3u); t += BIN_WG) s_hist[t] = 0u;   // (padded to four: bin_scan_relative)
     if (g == 0 && threadIdx.x == 0) bin_bookkeeping(a.cnt, slot);
     __syncthreads();
     const uint32_t n = draw_slots(a.cnt, fslot, fan_cap);
@@ -894,17 +730,52 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     const uint32_t lo = min(n, g * chunk), hi = min(n, lo + chunk);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    BinPut put{s_stage, a.bins, 0u, stage_cap, a.bin_cap};
-    bin_walk<false>(a, s_hist, a.pbox, lo, hi, lane, wave, put);
+#ifdef FRR_DEBUG_COUNTERS
+    const unsigned long long d_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    bin_walk<false>(a, s_hist, a.pbox, lo, hi, lane, wave, PutNone{});
     __syncthreads();
-    uint32_t base, total;
-    bin_reserve_publish(a, s_hist, ntiles, seg + (size_t)g * (ntiles + 1), slot, s_w, &s_base, lane, wave, base, total);
-    put.region = base;
-    bin_walk<true>(a, s_hist, a.pbox, lo, hi, lane, wave, put);
-    __syncthreads();
+#ifdef FRR_DEBUG_COUNTERS
+    const unsigned long long d_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const uint32_t total = bin_scan_relative(s_hist, ntiles, s_w, lane, wave);
+#ifdef FRR_DEBUG_COUNTERS
+    const unsigned long long d_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // the region is reserved now, but only a workgroup whose records do not all fit the LDS staging has to know where it
+    // starts before it places them: the others walk while the atomic is in flight
+    unsigned long long before = 0;
+    if (threadIdx.x == 0) before = atomicAdd(&a.cnt->seg_total[slot], (unsigned long long)total);
+    uint32_t base = 0;
+    if (total > stage_cap) {
+        if (threadIdx.x == 0) s_base = bin_region_of(a, before, total);
+        __syncthreads();
+        base = s_base;
+        bin_walk<true>(a, s_hist, a.pbox, lo, hi, lane, wave, PutMixed{s_stage, a.bins, base, stage_cap, a.bin_cap});
+        __syncthreads();
+    } else {
+        bin_walk<true>(a, s_hist, a.pbox, lo, hi, lane, wave, PutStaged{s_stage});
+        if (threadIdx.x == 0) s_base = bin_region_of(a, before, total);
+        __syncthreads();
+        base = s_base;
+    }
+#ifdef FRR_DEBUG_COUNTERS
+    const unsigned long long d_t3 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // the row of the segment table: tile t starts where tile t-1 ended (every cursor has run to the end of its tile)
+    uint32_t *__restrict__ row = seg + (size_t)g * (ntiles + 1);
+    for (uint32_t t = threadIdx.x; t <= ntiles; t += BIN_WG) row[t] = min(base + (t ? s_hist[t - 1] : 0u), a.bin_cap);
     const uint32_t nstaged = min(total, stage_cap);
     for (uint32_t j = threadIdx.x; j < nstaged; j += BIN_WG)
         if (base + j < a.bin_cap) a.bins[base + j] = s_stage[j];
+#ifdef FRR_DEBUG_COUNTERS
+    if (threadIdx.x == 0) { // phase times of the binning workgroups, 10 ns units (tools/tile_timeline.py prints the sums)
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long d_t4 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *d = a.cnt->dbg[blockIdx.x % DBG_COPIES];
+        atomicAdd(d + 21, d_t1 - d_t0); atomicAdd(d + 22, d_t2 - d_t1); atomicAdd(d + 23, ((d_t3 - d_t2) << 32) | (d_t4 - d_t3));
+    }
+#endif
 }
 
 } // namespace frr

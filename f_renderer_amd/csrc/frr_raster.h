@@ -380,19 +380,6 @@ constexpr int LIGHT_NW = FRR_LIGHT_NW; // waves per tile of the shape for lightl
 constexpr int LIGHT_B = FRR_LIGHT_B;
 constexpr int SPAN_AQ_MIN = FRR_SPAN_AQ_MIN; // survivors a wave collects before it rasterizes them (1: after every cull step)
 
-// wave64 inclusive prefix sum on the DPP network (row_shr within 16-lane rows, then row broadcasts)
-__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x)
-{
-    uint32_t v = x;
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
-    return v;
-}
-
 // A wave's LDS instructions execute in issue order, so lanes of ONE wave may exchange data through
 // LDS without waiting; this fence only keeps the compiler from reordering the accesses.
 __device__ __forceinline__ void wave_lds_fence()

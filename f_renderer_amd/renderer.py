@@ -121,8 +121,6 @@ def _options_from_env():
                       ("FRR_ENT_SLOT", "tile_slot_records"), ("FRR_BIN_CAP", "bin_capacity")):
         if e.get(var):
             o[name] = int(e[var])
-    if e.get("FRR_FUSE") == "1":
-        o["fuse_geometry_binning"] = 1
     if e.get("FRR_CLEAR") == "eager":
         o["clear_eager"] = 1
     if e.get("FRR_BIN") == "atomics":
@@ -317,7 +315,7 @@ class Renderer:
         self._check(self._lib.frr_event_elapsed_ms(self._ctx, a, b, C.byref(ms)))
         return float(ms.value)
 
-    KERNELS = ("k_clear", "k_geom", "k_geom_scan", "k_geom_bin", "k_bin_count",
+    KERNELS = ("k_clear", "k_geom", "k_geom_scan", "k_bin_count",
                "k_tile_scan", "k_bin_fill", "k_raster", "k_bin_seg")
 
     def profile_enable(self, on=True, kernels=None, period=1):

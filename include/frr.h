@@ -200,12 +200,11 @@ int frr_event_elapsed_ms(frr_ctx *ctx, int a, int b, float *ms);
  *   "bin_atomics"             1: global-atomic CSR binning (the path for windows of more than 36,864 tiles)
  *   "bin_capacity"            initial capacity of the (triangle, tile) lists in records (overflow / re-issue tests)
  *   "tile_slot_records"       records per tile slot of the near-first copy (tests of its overflow arena)
- *   "fuse_geometry_binning"   1: frr_draw sets up and bins in one launch (k_geom_bin; measured slower, default 0)
  *   "clear_eager"             1: frr_clear runs its own kernel at once instead of riding on the next full-window draw */
 int frr_set_option(frr_ctx *ctx, const char *name, int64_t value);
 /* per-kernel accumulated device time (ms) and launch count since frr_profile_reset.  `mask`:
  * 0 = off, -1 = every kernel, else OR of (1 << index) with index in the order k_clear,
- * k_geom, k_geom_scan, k_geom_bin, k_bin_count, k_tile_scan, k_bin_fill, k_raster,
+ * k_geom, k_geom_scan, k_bin_count, k_tile_scan, k_bin_fill, k_raster,
  * k_bin_seg.  A profiled launch is bracketed by two HIP events on the ctx stream. */
 int frr_profile_enable(frr_ctx *ctx, int mask);
 /* bracket only every `period`-th launch of each selected kernel (default 1): an event pair costs the

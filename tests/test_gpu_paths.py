@@ -203,16 +203,13 @@ def test_fan_capacity_overflow_is_reported_then_recovers(oracle):
     assert r.stats()["tris_setup"] == f.counters.tris_setup
 
 
-@pytest.mark.parametrize("fuse", ["1", "0"])
 @pytest.mark.parametrize("scene", ["clip_heavy", "phong", "many_rounds"])
-def test_fused_and_separate_geometry_binning_agree_with_oracle(oracle, monkeypatch, fuse, scene):
-    """FRR_FUSE=1 makes frr_draw set up and bin in ONE launch (k_geom_bin) when it can; the default keeps the two kernels
-    (k_geom_single + k_bin_seg) that frr_geometry + frr_raster always use.  Both must give the oracle's bits: setup
-    records, ids, depth, colour -- with clipped fans, a textured mesh (K = 8 varyings through the fused kernel's staging)
-    and a mesh of several rounds per workgroup (600k triangles)."""
+def test_draw_of_clipped_textured_and_many_round_meshes(oracle, scene):
+    """frr_draw (geometry + segmented binning + tile kernel) twice in a row -- the per-draw slots alternate -- on clipped
+    fans, a textured mesh (K = 8 varyings) and a mesh of 600k triangles: setup records, ids, depth and colour are the
+    oracle's bits."""
     import f_renderer_amd as fr
     from f_renderer_amd import scenes
-    monkeypatch.setenv("FRR_FUSE", fuse)
     if scene == "phong":
         W, H = 320, 200
         mesh = scenes.displaced_sphere(n=60)
