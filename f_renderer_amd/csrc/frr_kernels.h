@@ -137,7 +137,9 @@ __device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, c
     };
     const uint4 mine = make_uint4(i, pb.z, pb.x, pb.y);
     // footprints of at most 2x2 tiles (the common case) as straight-line code: up to four
-    // independent LDS atomics in flight instead of a loop of dependent atomic -> store steps
+    // independent LDS atomics in flight instead of a loop of dependent atomic -> store steps.  (A second straight-line
+    // form for 3x3 footprints cost more than it saved: nearly every wave has ONE such lane and then runs all nine
+    // predicated positions; 25.9 -> 23.0 us per launch on the 1080p frame without it.)
     const bool small = nt > 0 && ntx <= 2 && nty <= 2;
     if (small) {
         const bool own0 = owns_tile_row(t.ty0, a.rank, a.world, a.rpr);
@@ -159,29 +161,8 @@ __device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, c
             if (v3) atomicAdd(&s_hist[t10 + 1], 1u);
         }
     }
-    // footprints up to 3x3 tiles, same idea (nine predicated positions); skipped by waves without any
-    const bool mid = nt > 0 && !small && ntx <= 3 && nty <= 3;
-    if (__ballot(mid)) {
-        uint32_t pos[9];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const bool own = mid && dy < nty && owns_tile_row(t.ty0 + dy, a.rank, a.world, a.rpr);
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const bool v = own && dx < ntx;
-                const int tile = local_tile_row(t.ty0 + dy, a.rank, a.world, a.rpr) * a.tiles_x + t.tx0 + dx;
-                pos[dy * 3 + dx] = ~0u;
-                if constexpr (SCATTER) { if (v) pos[dy * 3 + dx] = atomicAdd(&s_hist[tile], 1u); }
-                else { if (v) atomicAdd(&s_hist[tile], 1u); }
-            }
-        }
-        if constexpr (SCATTER) {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) put(pos[q], mine);
-        }
-    }
     // larger footprints: four at a time, each spread over a quarter of the wave (16 lanes)
-    unsigned long long big = __ballot(nt > 0 && !small && !mid);
+    unsigned long long big = __ballot(nt > 0 && !small);
     while (big) {
         int src = -1;
 #pragma unroll
@@ -191,33 +172,51 @@ __device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, c
             if ((lane >> 4) == j) src = sj;
         }
         const int sl = src < 0 ? 0 : src;
-        const int bx0 = __shfl(t.tx0, sl), by0 = __shfl(t.ty0, sl), bnx = __shfl(ntx, sl);
-        const int bnt_src = __shfl(nt, sl); // unconditional: a cross-lane read must not sit under `src >= 0` (inactive source lanes read as 0)
-        const int bnt = src < 0 ? 0 : bnt_src;
+        // (cross-lane reads are unconditional: they must not sit under `src >= 0`, inactive source lanes read as 0)
+        const uint32_t o0 = __shfl((uint32_t)t.tx0 | ((uint32_t)t.ty0 << 16), sl);   // tile coordinates are below 1024
+        const uint32_t o1 = __shfl((uint32_t)ntx | ((uint32_t)nty << 16), sl);
+        const int bx0 = (int)(o0 & 0xFFFFu), by0 = (int)(o0 >> 16), bnx = (int)(o1 & 0xFFFFu);
+        const int bnt = src < 0 ? 0 : bnx * (int)(o1 >> 16);
         const uint4 ent = make_uint4(base + sl, __shfl(pb.z, sl), __shfl(pb.x, sl), __shfl(pb.y, sl));
-        for (int q = lane & 15; q < bnt; q += 16) visit(ent, bx0 + q % bnx, by0 + q / bnx);
+        // q -> (q % bnx, q / bnx) through a 1-ulp reciprocal: (q + 0.5) / bnx is at least 0.5 / bnx away from an integer
+        const float inv = __builtin_amdgcn_rcpf((float)bnx);
+        for (int q = lane & 15; q < bnt; q += 16) {
+            const int qy = (int)(((float)q + 0.5f) * inv);
+            visit(ent, bx0 + (q - qy * bnx), by0 + qy);
+        }
     }
 }
 
-// the slots [lo, hi) of `pbox`, by the waves of a BIN_WG-thread workgroup
+// The slots [lo, hi) of `pbox`, by the waves of a BIN_WG-thread workgroup: a wave takes 64 consecutive slots per round,
+// BIN_PF rounds at a time -- their bboxes are fetched up front (the loop is latency-bound otherwise).
+constexpr int BIN_PF = 4;
+__device__ __forceinline__ void bin_load(const uint4 *__restrict__ pbox, uint32_t base0, uint32_t hi, int lane, uint4 (&pb)[BIN_PF])
+{
+#pragma unroll
+    for (int k = 0; k < BIN_PF; ++k) {
+        const uint32_t i = base0 + k * BIN_WG + lane;
+        pb[k] = i < hi ? pbox[i] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
+    }
+}
+template <bool SCATTER, class PUT>
+__device__ __forceinline__ void bin_rounds(const RasterArgs &a, uint32_t *s_hist, const uint4 (&pb)[BIN_PF], uint32_t base0, uint32_t hi,
+                                           int lane, const PUT &put)
+{
+#pragma unroll
+    for (int k = 0; k < BIN_PF; ++k) {
+        const uint32_t base = base0 + k * BIN_WG;
+        if (base >= hi) break;
+        bin_one<SCATTER>(a, s_hist, pb[k], base, lane, put);
+    }
+}
 template <bool SCATTER, class PUT>
 __device__ __forceinline__ void bin_walk(const RasterArgs &a, uint32_t *s_hist, const uint4 *__restrict__ pbox, uint32_t lo, uint32_t hi,
                                          int lane, uint32_t wave, const PUT &put)
 {
-    constexpr int PF = 4; // bboxes of PF rounds are fetched up front: the loop is latency-bound otherwise
-    for (uint32_t base0 = lo + wave * 64u; base0 < hi; base0 += PF * BIN_WG) {
-        uint4 pb[PF];
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const uint32_t i = base0 + k * BIN_WG + lane;
-            pb[k] = i < hi ? pbox[i] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
-        }
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const uint32_t base = base0 + k * BIN_WG;
-            if (base >= hi) break;
-            bin_one<SCATTER>(a, s_hist, pb[k], base, lane, put);
-        }
+    for (uint32_t base0 = lo + wave * 64u; base0 < hi; base0 += BIN_PF * BIN_WG) {
+        uint4 pb[BIN_PF];
+        bin_load(pbox, base0, hi, lane, pb);
+        bin_rounds<SCATTER>(a, s_hist, pb, base0, hi, lane, put);
     }
 }
 
@@ -733,6 +732,8 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
 #ifdef FRR_DEBUG_COUNTERS
     const unsigned long long d_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    // (keeping the chunk's bboxes in registers from the counting walk to the placing walk saved nothing: the second read
+    // comes from L2 and the 16 extra registers cost the 4096^2 frame 2 us)
     bin_walk<false>(a, s_hist, a.pbox, lo, hi, lane, wave, PutNone{});
     __syncthreads();
 #ifdef FRR_DEBUG_COUNTERS
