@@ -42,7 +42,7 @@ struct Counters {
     uint64_t bin_entries_frame;
     uint32_t draws;
     uint32_t need_fans;     // fan slots the current draw needs (valid even on overflow)
-    uint32_t done_ctr;      // fused geometry + binning launch: workgroups that have finished (the last one scans the block sums)
+    uint32_t reserved0;
     uint32_t skip_prev_bins; // set by the frame reset: the other binning slot holds the PREVIOUS frame's count, not to be added
     unsigned long long seg_total[2]; // segmented binning: entries reserved by the current / previous draw (slots alternate per draw)
     uint32_t fan_cursor[2];          // fan slots handed out by the current / previous draw's geometry kernel (slots alternate)

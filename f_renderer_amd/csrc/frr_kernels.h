@@ -469,7 +469,7 @@ __device__ __forceinline__ void geom_bookkeeping(const GeomArgs &g)
 template <int VS>
 __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUniforms u)
 {
-    __shared__ uint32_t s_w[4], s_wf[4];
+    __shared__ uint32_t s_w[4];
     __shared__ uint4 s_stage[GEOM_BLOCK / 64][64 * 5];    // per wave: 64 records at an 80-byte stride (see the record stores)
     __shared__ float s_cxy[GEOM_BLOCK / 64][CLIP_MAXV][2]; // per wave: clip x,y in list order
     __shared__ int32_t s_ckey[GEOM_BLOCK / 64][CLIP_MAXV];
@@ -491,9 +491,11 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
         for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
         n = classify(pos, clipped);
     }
-    uint32_t total, ftotal;
-    const uint32_t eoff = block_excl_scan256(n, s_w, total);                    // emission offset within the block
-    const uint32_t foff = block_excl_scan256(clipped ? n : 0u, s_wf, ftotal);   // fan slots of the clipped inputs before this one
+    // ONE block scan for two prefix sums: emission offset within the block (low half) and fan slots of the clipped inputs
+    // before this one (high half); an input emits at most 19 triangles, so a block's sums stay below 2^13
+    uint32_t ptotal;
+    const uint32_t poff = block_excl_scan256(n | ((clipped ? n : 0u) << 16), s_w, ptotal);
+    const uint32_t eoff = poff & 0xFFFFu, foff = poff >> 16, total = ptotal & 0xFFFFu, ftotal = ptotal >> 16;
     if (threadIdx.x == 0) {
         g.block_sums[bid] = total;
         s_fbase = ftotal ? atomicAdd(&g.cnt->fan_cursor[g.fslot], ftotal) : 0u;  // ONE returning atomic per block that clips anything
@@ -573,7 +575,6 @@ __global__ void k_geom_empty(GeomArgs g)
 // Exclusive scan of the draw's block sums (in place: they become Counters::block_prefix), by one workgroup of 1024
 // threads (the extra workgroup of k_bin_seg, or k_geom_scan on its own); publishes n_emit and raises the capacity flag
 // when the draw asked for more fan slots than there are.
-template <bool AGENT = false>
 __device__ __forceinline__ void geom_scan(uint32_t *sums, uint32_t nblocks, Counters *cnt, int fslot, uint32_t fan_cap)
 {
     __shared__ uint32_t s_sw[16];
@@ -583,9 +584,7 @@ __device__ __forceinline__ void geom_scan(uint32_t *sums, uint32_t nblocks, Coun
     __syncthreads();
     for (uint32_t base = 0; base < nblocks; base += 1024) {
         uint32_t i = base + threadIdx.x;
-        // AGENT: the sums were stored by other workgroups of this very launch (write-through stores, counted in by an
-        // agent-scope atomic): read them past this CU's L1
-        uint32_t v = i < nblocks ? (AGENT ? __hip_atomic_load(&sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : sums[i]) : 0u;
+        uint32_t v = i < nblocks ? sums[i] : 0u;
         uint32_t inc = wave_incl_scan(v);
         if (lane == 63) s_sw[w] = inc;
         __syncthreads();
