@@ -73,6 +73,9 @@ struct frr_ctx {
     RasterRec *recs = nullptr; size_t setup_cap = 0;            // [input triangles + fan capacity]
     float *vary = nullptr; size_t vary_cap = 0; // floats
     uint4 *pbox = nullptr; size_t pbox_cap = 0;
+    uint2 *clipq = nullptr; size_t clipq_cap = 0;               // [input triangles] the clip kernel's queue (GeomArgs::clipq)
+    int clip_queue = -1;        // option clip_queue: 1 use the queue + k_geom_clip, 0 never, -1 when the latest counters read back
+    bool clip_queue_auto = false; //   showed a block with more than CLIP_QUEUE_AT clipped inputs (results are the same either way)
     // binning workspace
     uint32_t *tile_counts = nullptr, *tile_offsets = nullptr, *tile_cursor = nullptr;
     uint32_t max_tiles = 0;
@@ -198,12 +201,14 @@ void refresh_dev_uniforms(frr_ctx *c)
     else { d.tex = nullptr; d.tex_w = d.tex_h = 0; }
 }
 
+constexpr uint32_t kClipGrid = 2048;      // workgroups of k_geom_clip (four wavefronts each, one triangle per wavefront and step)
 int check_frame_counters(frr_ctx *c, Counters *host)
 {
     Counters h;
     HIP_TRY(c, hipMemcpyAsync(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (host) *host = h;
+    c->clip_queue_auto = std::max(h.clip_block_max[0], h.clip_block_max[1]) > (uint32_t)CLIP_QUEUE_AT;
     if (h.overflow) {
         // grow what overflowed so that re-issuing the frame succeeds
         if (h.overflow & 2u) {
@@ -222,6 +227,7 @@ template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks
 {
     ProfScope p(c, KID_GEOM);
     hipLaunchKernelGGL(k_geom_single<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni);
+    if (g.use_clipq) hipLaunchKernelGGL(k_geom_clip<VS>, dim3(std::min<uint32_t>(kClipGrid, nblocks * 4u)), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni);
 }
 
 // the geometry kernel for the VS of the mesh
@@ -367,7 +373,7 @@ void frr_destroy(frr_ctx *c)
     prof_collect(c);
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
-    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->tinfo, c->fanbase, c->fan_okey, c->recs, c->vary, c->pbox,
+    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->tinfo, c->fanbase, c->fan_okey, c->recs, c->vary, c->pbox, c->clipq,
                     c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bins2, c->bin_matrix};
     for (void *p : ptrs) if (p) (void)hipFree(p);
 #ifdef FRR_DEBUG_COUNTERS
@@ -391,6 +397,7 @@ int frr_set_option(frr_ctx *c, const char *name, int64_t v)
     else if (n == "raster_occ") { if (v != 0 && v != 4 && v != 6 && v != 8) return fail(c, FRR_ERR_INVALID, "raster_occ: 0, 4, 6 or 8"); c->raster_occ = (int)v; }
     else if (n == "bin_chunks") { if (v < 0) return fail(c, FRR_ERR_INVALID, "bin_chunks >= 0"); c->bin_g = (int)std::min<int64_t>(v, BIN_MAX_G); }
     else if (n == "clear_eager") c->clear_eager = v != 0;
+    else if (n == "clip_queue") { if (v < -1 || v > 1) return fail(c, FRR_ERR_INVALID, "clip_queue: -1, 0 or 1"); c->clip_queue = (int)v; }
     else if (n == "tile_slot_records") { if (v < 0 || v > 0x7FFFFFFF) return fail(c, FRR_ERR_INVALID, "tile_slot_records out of range"); c->ent_slot_override = (uint32_t)v; }
     else if (n == "bin_atomics") c->bin_atomics = v != 0;
     else if (n == "bin_capacity") { if (v < 0) return fail(c, FRR_ERR_INVALID, "bin_capacity >= 0"); c->bin_cap_init = (size_t)v; }
@@ -614,6 +621,8 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     if ((rc = ensure(c, c->recs, c->setup_cap, std::max<size_t>(slots, 1024))) != FRR_OK) return rc;
     if ((rc = ensure(c, c->pbox, c->pbox_cap, c->setup_cap)) != FRR_OK) return rc;
     if (K > 0 && (rc = ensure(c, c->vary, c->vary_cap, (size_t)c->setup_cap * 3 * 8 /* K <= 8 in the shader table */)) != FRR_OK) return rc;
+    const bool use_clipq = nt > 0 && (c->clip_queue > 0 || (c->clip_queue < 0 && c->clip_queue_auto));
+    if (use_clipq && (rc = ensure(c, c->clipq, c->clipq_cap, (size_t)nt)) != FRR_OK) return rc;
     GeomArgs g;
     g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
     g.fan_cap = (uint32_t)fan_cap;
@@ -630,6 +639,7 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     g.fslot = slot;
     g.block_sums = c->block_sums; g.tinfo = c->tinfo; g.fanbase = c->fanbase; g.fan_okey = c->fan_okey;
     g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;
+    g.clipq = c->clipq; g.use_clipq = use_clipq ? 1 : 0;
     // what the setup list about to be built was filtered by (frr_raster / frr_readback_setup check it)
     c->geom_filter = frr_ctx::GeomFilter{filter, fy0, fy1, c->rank, c->world, c->part_blocked};
     c->geom_slot = slot;

@@ -47,6 +47,8 @@ struct Counters {
     unsigned long long seg_total[2]; // segmented binning: entries reserved by the current / previous draw (slots alternate per draw)
     uint32_t fan_cursor[2];          // fan slots handed out by the current / previous draw's geometry kernel (slots alternate)
     uint32_t ent_cursor[2];          // tile kernel: space handed out in the overflow arena of bins2 (same slots)
+    uint32_t clip_q[2];              // geometry: clipped inputs handed to the clip kernel's queue (GeomArgs::clipq; same slots as fan_cursor)
+    uint32_t clip_block_max[2];      // geometry: the most clipped inputs any one 256-triangle block had (the host's hint for that queue)
     // per-draw tables the tile kernel's resolve reads (set by the geometry kernel; kernel arguments would cost it registers)
     const uint32_t *tinfo;           // [ntris] fan size (bits 0-4) | emission offset within its 256-triangle block (bits 5..)
     const uint32_t *fanbase;         // [ntris] clipped inputs: first fan slot, relative to ntris_draw
@@ -99,6 +101,8 @@ struct GeomArgs {
     uint32_t *fan_okey;     // [fan_cap]
     RasterRec *recs;        // [ntris + fan_cap]
     float *vary;            // [ntris + fan_cap][3][K]
+    uint2 *clipq;           // use_clipq: {input triangle, its first fan slot} of the clipped inputs a block does not expand itself
+    int32_t use_clipq;      //   (k_geom_clip expands them, one wavefront each, balanced over the chip); 0: every block expands all of its own
     uint4 *pbox;            // per slot, the binning input: {minx|miny<<16, maxx|maxy<<16 (i16 pixel bbox of spi), zkey of an upper bound of |rhw|, 0}; all zero = nothing here
     Counters *cnt;
 };
@@ -301,7 +305,7 @@ struct ScreenVtx { float rhw, ndcx, ndcy, sx, sy; int32_t ix, iy; };
 __device__ __forceinline__ ScreenVtx to_screen(const float pos[4], float fw, float fh)
 {
     ScreenVtx v;
-    v.rhw = 1.0f / pos[3];
+    v.rhw = recip_exact(pos[3]);                 // == 1.0f / w, bit for bit (frr_exact.h; checked for all 2^32 operands on the device)
     v.ndcx = pos[0] * v.rhw;
     v.ndcy = pos[1] * v.rhw;
     v.sx = (v.ndcx + 1.0f) * fw * 0.5f;

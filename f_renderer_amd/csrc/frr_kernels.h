@@ -274,6 +274,8 @@ __device__ __forceinline__ uint32_t bin_region_of(const RasterArgs &a, unsigned 
 // lanes 0..17 = the 3 pairs x 6 planes in the reference's loop order, lanes 18..20 = the originals,
 // so "list order" is simply lane order among the kept lanes.
 constexpr int CLIP_MAXV = 21;
+constexpr int CLIP_QUEUE_AT = 16;   // clipped inputs in one block from which on the block reports itself (the host then switches the clip queue on)
+constexpr int CLIP_INBLOCK = GEOM_BLOCK / 64;   // clipped inputs a geometry block expands itself when the clip queue is in use
 
 // Returns the lane's binning record (all zero for lanes that emit no fan triangle).
 template <int VS>
@@ -460,6 +462,7 @@ __device__ __forceinline__ void geom_bookkeeping(const GeomArgs &g)
     cnt->tri_base += cnt->n_emit;          // the previous draw's triangles precede this draw's (its block sums are scanned by now)
     cnt->n_emit = 0u;
     cnt->fan_cursor[g.fslot ^ 1] = 0u;
+    cnt->clip_q[g.fslot ^ 1] = 0u; cnt->clip_block_max[g.fslot ^ 1] = 0u;
     cnt->ntris_draw = g.ntris;
     cnt->tinfo = g.tinfo; cnt->fanbase = g.fanbase; cnt->fan_okey = g.fan_okey; cnt->block_prefix = g.block_sums;
     cnt->tris_in += g.ntris;
@@ -475,6 +478,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     __shared__ int32_t s_ckey[GEOM_BLOCK / 64][CLIP_MAXV];
     __shared__ float s_cv[GEOM_BLOCK / 64][CLIP_MAXV][7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)];
     __shared__ uint32_t s_cl[GEOM_BLOCK];                 // the block's clipped inputs: thread | fan offset within the block << 8
+    __shared__ uint32_t s_slot[GEOM_BLOCK / 64][64];      // per wave: the slot of the k-th lane that stores a record (when they are not a run)
     __shared__ uint32_t s_ncl, s_fbase;
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K;
     const uint32_t bid = blockIdx.x;
@@ -496,18 +500,17 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     uint32_t ptotal;
     const uint32_t poff = block_excl_scan256(n | ((clipped ? n : 0u) << 16), s_w, ptotal);
     const uint32_t eoff = poff & 0xFFFFu, foff = poff >> 16, total = ptotal & 0xFFFFu, ftotal = ptotal >> 16;
+    // ONE returning atomic per block that clips anything.  Device atomics on one address are served one after the other
+    // (~17 ns each): when most blocks of a mesh clip something -- a mesh that crosses the frustum -- that is many
+    // microseconds of queueing, so the result is not waited for here: the block sets up and stores its unclipped
+    // triangles first (the 250,000-triangle sheets of the 4K frame: 44 -> ... us)
+    uint32_t fbase_pending = 0u;
     if (threadIdx.x == 0) {
         g.block_sums[bid] = total;
-        s_fbase = ftotal ? atomicAdd(&g.cnt->fan_cursor[g.fslot], ftotal) : 0u;  // ONE returning atomic per block that clips anything
+        if (ftotal) fbase_pending = atomicAdd(&g.cnt->fan_cursor[g.fslot], ftotal);
     }
     if (t < g.ntris) g.tinfo[t] = n | (eoff << FAN_BITS);
-    __syncthreads();
-    const uint32_t fbase = s_fbase;
-    const bool fans_ok = fbase + ftotal <= g.fan_cap;  // else the frame is flagged invalid by geom_scan (cursor > capacity) and re-issued
-    if (clipped) {
-        g.fanbase[t] = fbase + foff;
-        if (fans_ok) s_cl[atomicAdd(&s_ncl, 1u)] = threadIdx.x | (foff << 8);
-    }
+    if (clipped) s_cl[atomicAdd(&s_ncl, 1u)] = threadIdx.x | (foff << 8);
     // Multi-GPU: a rank that owns none of the tile rows an (unclipped) triangle's bbox touches never reads its record
     // (geometry is replicated, so this is what keeps the replicated part small); clipped fans are kept on every rank
     ScreenVtx s0 = {}, s1 = {}, s2 = {};
@@ -523,46 +526,110 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     g.pbox[t] = so.pbox;
     const uint4 q0 = so.q0, q1 = so.q1, q2 = so.q2, q3 = so.q3;
     auto in_slot_f = [&](int sl, float x0, float x1, float x2) { return so.d0 == sl ? x0 : (so.d1 == sl ? x1 : x2); };
+    const unsigned long long am = __ballot(true);
+    const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+    const int np = __popcll(am);
+    const uint32_t t0 = __builtin_amdgcn_readfirstlane(t);
+    const bool run = __ballot(t == t0 + (uint32_t)rk) == am;   // the lanes here hold consecutive slots t0, t0+1, ...
+    // The lanes that are here write the record of their own slot t.  A lane-per-record store writes 16 B at a 64-B stride
+    // (64 partial-line writes per instruction, write-through); staged through the wave's LDS (80-B record stride:
+    // conflict-free b128 writes) and read back four lanes per record, the same bytes leave as whole records -- as one
+    // contiguous range when the lanes hold a run of consecutive slots (the usual case: every lane), else record by record
+    // at the slots listed in s_slot (meshes with culled or clipped triangles in between: most waves of the 4K frame).
+    uint4 *const st = s_stage[threadIdx.x >> 6];
+    uint32_t *const slots = s_slot[threadIdx.x >> 6];
+    if (!run) slots[rk] = t;
+    auto slot_at = [&](int r) { return run ? t0 + (uint32_t)r : slots[r]; };
     {
-        // The lanes that are here write the record of their own slot t; when they are a run of consecutive lanes (the
-        // usual case: every lane) the records are consecutive in memory.  A lane-per-record store writes 16 B at a 64-B
-        // stride (64 partial-line writes per instruction, write-through); staged through LDS (80-B record stride:
-        // conflict-free b128 writes) the same bytes leave as fully coalesced stores.
-        const unsigned long long am = __ballot(true);
-        const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-        const int np = __popcll(am);
-        const uint32_t t0 = __builtin_amdgcn_readfirstlane(t);
-        if (__ballot(t == t0 + (uint32_t)rk) == am) {
-            uint4 *st = s_stage[threadIdx.x >> 6];
-            st[rk * 5 + 0] = q0; st[rk * 5 + 1] = q1; st[rk * 5 + 2] = q2; st[rk * 5 + 3] = q3;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint4 *dst = reinterpret_cast<uint4 *>(g.recs + t0);
+        st[rk * 5 + 0] = q0; st[rk * 5 + 1] = q1; st[rk * 5 + 2] = q2; st[rk * 5 + 3] = q3;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int c = rk + j * np; dst[c] = st[(c >> 2) * 5 + (c & 3)]; }
-        } else {
-            uint4 *dst = reinterpret_cast<uint4 *>(g.recs + t);
-            dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
+        for (int j = 0; j < 4; ++j) {
+            const int c = rk + j * np, r = c >> 2;
+            reinterpret_cast<uint4 *>(g.recs + slot_at(r))[c & 3] = st[r * 5 + (c & 3)];
         }
     }
     if constexpr (K > 0) {
-        float *o = g.vary + (size_t)t * (3 * K);
+        float vv[3 * K];
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int k = 0; k < K; ++k) o[s * K + k] = in_slot_f(s, ctx[0][k], ctx[1][k], ctx[2][k]);
+            for (int k = 0; k < K; ++k) vv[s * K + k] = in_slot_f(s, ctx[0][k], ctx[1][k], ctx[2][k]);
+        if constexpr (K == 8) {
+            // 96 bytes of varyings per triangle: stored lane by lane that is 24 four-byte writes at a 96-byte stride
+            // (partial lines); staged the same way, 32 triangles at a time at a 7 x 16-byte stride, they leave six lanes
+            // per triangle as 16-byte stores
+            for (int lo = 0; lo < np; lo += 32) {
+                const int nh = min(np - lo, 32);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (the staging is in use again)
+                __builtin_amdgcn_wave_barrier();
+                if (rk >= lo && rk < lo + 32) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j)
+                        st[(rk - lo) * 7 + j] = make_uint4(f2u(vv[4 * j]), f2u(vv[4 * j + 1]), f2u(vv[4 * j + 2]), f2u(vv[4 * j + 3]));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int c = rk; c < nh * 6; c += np) {
+                    const int tri = (c * 171) >> 10, part = c - tri * 6;   // c / 6, c % 6 for c < 192
+                    reinterpret_cast<uint4 *>(g.vary + (size_t)slot_at(lo + tri) * (3 * K))[part] = st[tri * 7 + part];
+                }
+            }
+        } else {
+            float *o = g.vary + (size_t)t * (3 * K);
+#pragma unroll
+            for (int q = 0; q < 3 * K; ++q) o[q] = vv[q];
+        }
     }
     } // emit
     // the block's clipped inputs, one wave per triangle (lanes = candidate vertices)
+    if (threadIdx.x == 0) s_fbase = fbase_pending;
     __syncthreads();
-    const uint32_t ncl = s_ncl;
+    const uint32_t fbase = s_fbase;
+    const bool fans_ok = fbase + ftotal <= g.fan_cap;  // else the frame is flagged invalid by geom_scan (cursor > capacity) and re-issued
+    if (clipped) g.fanbase[t] = fbase + foff;
+    const uint32_t ncl = fans_ok ? s_ncl : 0u;
     if (ncl) {
+        // Meshes clip along lines that follow their index order (a grid sheet crossing a frustum plane: whole runs of
+        // consecutive triangles), so some blocks have hundreds of clipped inputs and most have none: expanded where they
+        // are, those blocks are the kernel's tail.  With the queue in use a block expands CLIP_INBLOCK of its own (one
+        // per wave) and hands the rest to k_geom_clip.
+        uint32_t nin = ncl;
+        if (threadIdx.x == 0 && ncl > (uint32_t)CLIP_QUEUE_AT) atomicMax(&g.cnt->clip_block_max[g.fslot], ncl);   // (few blocks: see above)
+        if (g.use_clipq && ncl > (uint32_t)CLIP_INBLOCK) {
+            nin = CLIP_INBLOCK;
+            if (threadIdx.x == 0) s_fbase = atomicAdd(&g.cnt->clip_q[g.fslot], ncl - nin);   // (s_fbase has been read by everyone)
+            __syncthreads();
+            const uint32_t qb = s_fbase;
+            for (uint32_t i = threadIdx.x; i < ncl - nin; i += GEOM_BLOCK) {
+                const uint32_t en = s_cl[nin + i];
+                g.clipq[qb + i] = make_uint2(bid * GEOM_BLOCK + (en & 255u), fbase + (en >> 8));
+            }
+        }
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        for (uint32_t e = (uint32_t)w; e < ncl; e += GEOM_BLOCK / 64) {
+        for (uint32_t e = (uint32_t)w; e < nin; e += GEOM_BLOCK / 64) {
             const uint32_t en = s_cl[e];
             (void)clip_triangle_wave<VS>(g, u, bid * GEOM_BLOCK + (en & 255u), fbase + (en >> 8), lane, s_cxy[w], s_ckey[w], s_cv[w]);
         }
+    }
+}
+
+// the clipped inputs the geometry blocks queued (GeomArgs::use_clipq), one wavefront per triangle over the whole chip
+template <int VS>
+__global__ __launch_bounds__(GEOM_BLOCK) void k_geom_clip(GeomArgs g, DevUniforms u)
+{
+    __shared__ float s_cxy[GEOM_BLOCK / 64][CLIP_MAXV][2];
+    __shared__ int32_t s_ckey[GEOM_BLOCK / 64][CLIP_MAXV];
+    __shared__ float s_cv[GEOM_BLOCK / 64][CLIP_MAXV][7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)];
+    const uint32_t n = g.cnt->clip_q[g.fslot];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t stride = gridDim.x * (GEOM_BLOCK / 64);
+    for (uint32_t e = blockIdx.x * (GEOM_BLOCK / 64) + (uint32_t)w; e < n; e += stride) {
+        const uint2 q = g.clipq[e];
+        (void)clip_triangle_wave<VS>(g, u, q.x, q.y, lane, s_cxy[w], s_ckey[w], s_cv[w]);
     }
 }
 

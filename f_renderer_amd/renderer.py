@@ -118,7 +118,7 @@ def _options_from_env():
     if e.get("FRR_RASTER") == "sweep":
         o["raster_sweep"] = 1
     for var, name in (("FRR_RASTER_NW", "raster_nw"), ("FRR_RASTER_OCC", "raster_occ"), ("FRR_BIN_G", "bin_chunks"),
-                      ("FRR_ENT_SLOT", "tile_slot_records"), ("FRR_BIN_CAP", "bin_capacity")):
+                      ("FRR_ENT_SLOT", "tile_slot_records"), ("FRR_BIN_CAP", "bin_capacity"), ("FRR_CLIP_QUEUE", "clip_queue")):
         if e.get(var):
             o[name] = int(e[var])
     if e.get("FRR_CLEAR") == "eager":

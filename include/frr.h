@@ -200,6 +200,10 @@ int frr_event_elapsed_ms(frr_ctx *ctx, int a, int b, float *ms);
  *   "bin_atomics"             1: global-atomic CSR binning (the path for windows of more than 36,864 tiles)
  *   "bin_capacity"            initial capacity of the (triangle, tile) lists in records (overflow / re-issue tests)
  *   "tile_slot_records"       records per tile slot of the near-first copy (tests of its overflow arena)
+ *   "clip_queue"              1: clipped inputs beyond four per 256-triangle block are expanded by a second launch
+ *                             (k_geom_clip, one wavefront each over the whole chip) instead of by their block; 0: never;
+ *                             -1 (default): when the counters last read back (frr_sync, frr_readback, frr_get_stats)
+ *                             showed a block with more than 16 clipped inputs
  *   "clear_eager"             1: frr_clear runs its own kernel at once instead of riding on the next full-window draw */
 int frr_set_option(frr_ctx *ctx, const char *name, int64_t value);
 /* per-kernel accumulated device time (ms) and launch count since frr_profile_reset.  `mask`:

@@ -250,3 +250,55 @@ def test_draw_of_clipped_textured_and_many_round_meshes(oracle, scene):
         np.testing.assert_array_equal(g["spi"], setup["spi"])
         np.testing.assert_array_equal(g["spf"].view(np.uint32), setup["spf"].view(np.uint32))
         np.testing.assert_array_equal(g["rhw"].view(np.uint32), setup["rhw"].view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "auto"])
+def test_clip_queue_gives_the_same_setup_and_frame(oracle, monkeypatch, mode):
+    """Clipped inputs beyond four per block can be expanded by a second launch (k_geom_clip, option clip_queue) instead
+    of by their geometry block -- the tail of meshes that clip along their index order.  Forced on, forced off and in the
+    automatic mode (which switches on after a counter read-back has shown a block with many clipped inputs) the setup
+    records, ids, depth and colour are the oracle's bits: a scene where every second triangle clips, and the layered
+    sheets of config 5 (whole runs of consecutive clipped triangles) through the textured shader."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    if mode != "auto":
+        monkeypatch.setenv("FRR_CLIP_QUEUE", mode)
+    W, H = 300, 170
+    tris = scenes.random_clip_triangles(30000, W, H, seed=61, spread=1.25)
+    f = oracle.Frame(W, H)
+    f.clear()
+    setup = f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms(), keep_setup=True)
+    r = fr.Renderer(W, H)
+    m = r.upload_mesh(tris, fr.VS_CLIP)
+    for _ in range(3):                      # (auto: the first frame's read-back turns the queue on for the next)
+        r.clear()
+        r.draw(m, fr.PS_DEPTH)
+        _, d, t = r.readback()
+        np.testing.assert_array_equal(t, f.tri_id)
+        np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+        g = r.setup_triangles()
+        assert g.shape[0] == setup.shape[0]
+        np.testing.assert_array_equal(g["spi"], setup["spi"])
+        np.testing.assert_array_equal(g["rhw"].view(np.uint32), setup["rhw"].view(np.uint32))
+    cfg = scenes.build_config("cfg5", reduced=True)
+    W, H, mesh = cfg["W"], cfg["H"], cfg["mesh"]
+    eye, at, up, fovy, aspect, zn, zf = scenes.demo_camera(W, H)
+    r = fr.Renderer(W, H)
+    r.set_texture(0, cfg["tex"])
+    r.set_uniforms(view=fr.set_look_at(eye, at, up), proj=fr.set_perspective(fovy, aspect, zn, zf), view_pos=eye, texture_slot=0)
+    f = oracle.Frame(W, H)
+    u = oracle.make_uniforms(view=oracle.set_look_at(eye, at, up), proj=oracle.set_perspective(fovy, aspect, zn, zf),
+                             view_pos=eye, tex=oracle.Texture(cfg["tex"]))
+    f.clear()
+    setup = f.draw(mesh, oracle.VS_PHONG, oracle.PS_BLINN, u, keep_setup=True)
+    m = r.upload_mesh(mesh, fr.VS_PHONG)
+    for _ in range(2):
+        r.clear()
+        r.draw(m, fr.PS_BLINN)
+        c, d, t = r.readback()
+        np.testing.assert_array_equal(t, f.tri_id)
+        np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+        np.testing.assert_array_equal(c, f.color)
+        g = r.setup_triangles()
+        assert g.shape[0] == setup.shape[0]
+        np.testing.assert_array_equal(g["ctx"][..., :8].view(np.uint32), setup["ctx"][..., :8].view(np.uint32))
