@@ -605,15 +605,19 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     const uint64_t nt = m.ntris;
     int rc;
     if ((rc = scan_now(c)) != FRR_OK) return rc;   // the previous draw's n_emit feeds this draw's tri_base
-    // fan region: clipped inputs are the ones that straddle a frustum plane, usually few; room for as many fan triangles
+    // fan space: clipped inputs are the ones that straddle a frustum plane, usually few; room for as many fan triangles
     // as there are inputs (+ 4096) to start with, grown on demand (FRR_ERR_CAPACITY: the frame is re-issued) up to the
-    // worst case of 19 per input
-    // (meshes up to 55,000 triangles get their worst case outright: 2^20 slots are cheap)
-    uint64_t fan_cap = std::max<uint64_t>(std::max<uint64_t>(nt + 4096, std::min<uint64_t>(nt * FRR_MAX_OUT_TRIS, 1u << 20)), c->fan_hint);
-    fan_cap = std::min<uint64_t>(fan_cap, nt * FRR_MAX_OUT_TRIS);
-    if (nt + fan_cap > 0xFFFFFFF0ull) fan_cap = 0xFFFFFFF0ull - nt;
-    const size_t slots = (size_t)(nt + fan_cap);
+    // worst case of 19 per input (small meshes get their worst case outright: 2^20 slots are cheap) ...
     const uint32_t nblocks = (uint32_t)((nt + GEOM_BLOCK - 1) / GEOM_BLOCK);
+    // ... in FAN_REGIONS regions (block b allocates in region b % FAN_REGIONS: frr_device.h); a region never needs more
+    // than 19 slots for every input of the blocks that use it
+    const uint64_t region_worst = (uint64_t)FRR_MAX_OUT_TRIS * GEOM_BLOCK * ((nblocks + FAN_REGIONS - 1) / FAN_REGIONS);
+    uint64_t region = std::max<uint64_t>(std::max<uint64_t>((nt + 4096 + FAN_REGIONS - 1) / FAN_REGIONS, std::min<uint64_t>(region_worst, (1u << 20) / FAN_REGIONS)),
+                                         (c->fan_hint + FAN_REGIONS - 1) / FAN_REGIONS);
+    region = std::max<uint64_t>(std::min<uint64_t>(region, region_worst), 1);
+    uint64_t fan_cap = region * FAN_REGIONS;
+    if (nt + fan_cap > 0xFFFFFFF0ull) fan_cap = (0xFFFFFFF0ull - nt) / FAN_REGIONS * FAN_REGIONS;
+    const size_t slots = (size_t)(nt + fan_cap);
     if ((rc = ensure(c, c->block_sums, c->block_sums_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
     if ((rc = ensure(c, c->tinfo, c->tinfo_cap, (size_t)std::max<uint64_t>(nt, 1))) != FRR_OK) return rc;
     if ((rc = ensure(c, c->fanbase, c->fanbase_cap, (size_t)std::max<uint64_t>(nt, 1))) != FRR_OK) return rc;
@@ -835,15 +839,22 @@ int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uin
     // the records live at slots (frr_device.h): input t's own slot, or its fan's slots behind the inputs; walking the
     // inputs in order and each fan in order is the reference's emission order
     const uint64_t nt = c->geom_ntris;
-    const uint64_t slots = nt + std::min<uint64_t>(h.fan_cursor[c->geom_slot], c->geom_fan_cap);
+    const uint64_t slots = nt + c->geom_fan_cap;   // (fan slots are spread over the regions of the fan space)
     const int K = frr_vs_num_varyings(c->geom_vs);
     std::vector<uint32_t> tinfo(nt), fanbase(nt);
     std::vector<RasterRec> recs(slots);
     std::vector<float> vary((size_t)slots * 3 * K);
     if (nt) HIP_TRY(c, hipMemcpy(tinfo.data(), c->tinfo, nt * 4, hipMemcpyDeviceToHost));
     if (nt) HIP_TRY(c, hipMemcpy(fanbase.data(), c->fanbase, nt * 4, hipMemcpyDeviceToHost));
-    if (slots) HIP_TRY(c, hipMemcpy(recs.data(), c->recs, slots * sizeof(RasterRec), hipMemcpyDeviceToHost));
-    if (slots && K) HIP_TRY(c, hipMemcpy(vary.data(), c->vary, vary.size() * sizeof(float), hipMemcpyDeviceToHost));
+    // the inputs' own slots, then the used part of every fan region
+    const uint64_t region = c->geom_fan_cap / FAN_REGIONS;
+    for (int k = -1; k < FAN_REGIONS; ++k) {
+        const uint64_t first = k < 0 ? 0 : nt + (uint64_t)k * region;
+        const uint64_t count = k < 0 ? nt : std::min<uint64_t>(h.fan_cursor[c->geom_slot][k].v, region);
+        if (!count) continue;
+        HIP_TRY(c, hipMemcpy(recs.data() + first, c->recs + first, count * sizeof(RasterRec), hipMemcpyDeviceToHost));
+        if (K) HIP_TRY(c, hipMemcpy(vary.data() + first * 3 * K, c->vary + first * 3 * K, count * 3 * K * sizeof(float), hipMemcpyDeviceToHost));
+    }
     uint64_t i = 0;
     for (uint64_t t = 0; t < nt && i < cap_tris; ++t) {
         const uint32_t n = tinfo[t] & ((1u << FAN_BITS) - 1u);
@@ -873,6 +884,7 @@ int frr_get_stats(frr_ctx *c, frr_stats *out)
     Counters h;
     HIP_TRY(c, hipMemcpyAsync(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->clip_queue_auto = std::max(h.clip_block_max[0], h.clip_block_max[1]) > (uint32_t)CLIP_QUEUE_AT;
     out->tris_in = h.tris_in;
     out->tris_setup = (uint64_t)h.tri_base + h.n_emit;   // (settle() has scanned the latest draw's block sums)
     out->bin_entries = h.bin_entries_frame + h.seg_total[0] + h.seg_total[1];

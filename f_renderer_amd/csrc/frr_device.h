@@ -30,6 +30,15 @@ constexpr int DBG_COPIES = 256;
 constexpr int DBG_COPIES = 1;
 #endif
 
+// Fan slots (the triangles clipped inputs expand to) are handed out by ONE returning device atomic per geometry block that
+// clips anything.  Atomics on one address are served one after the other (~17 ns each), so a mesh in which most blocks
+// clip something -- any big mesh that crosses the frustum -- queued for as long as the rest of the kernel takes (977
+// blocks: 17 us).  The fan space is therefore FAN_REGIONS regions of fan_cap / FAN_REGIONS slots with a cursor each (on
+// its own cache line); block b allocates in region b % FAN_REGIONS.  Slot numbers stay unique, which is all the order
+// keys, the binning records and the read-back need; the binning walks the USED part of every region (FanMap).
+constexpr int FAN_REGIONS = 8;
+struct alignas(128) FanCursor { uint32_t v; uint32_t pad[31]; };
+
 struct Counters {
     uint32_t n_emit;        // triangles the current draw emits (the reference's count; known once the block sums are scanned)
     uint32_t tri_base;      // emission index of this draw's first triangle within the frame
@@ -45,7 +54,7 @@ struct Counters {
     uint32_t reserved0;
     uint32_t skip_prev_bins; // set by the frame reset: the other binning slot holds the PREVIOUS frame's count, not to be added
     unsigned long long seg_total[2]; // segmented binning: entries reserved by the current / previous draw (slots alternate per draw)
-    uint32_t fan_cursor[2];          // fan slots handed out by the current / previous draw's geometry kernel (slots alternate)
+    FanCursor fan_cursor[2][FAN_REGIONS]; // fan slots handed out per region by the current / previous draw's geometry kernel (slots alternate)
     uint32_t ent_cursor[2];          // tile kernel: space handed out in the overflow arena of bins2 (same slots)
     uint32_t clip_q[2];              // geometry: clipped inputs handed to the clip kernel's queue (GeomArgs::clipq; same slots as fan_cursor)
     uint32_t clip_block_max[2];      // geometry: the most clipped inputs any one 256-triangle block had (the host's hint for that queue)
@@ -89,7 +98,7 @@ struct GeomArgs {
     const float *in;        // [ntris][3][NF]
     uint32_t ntris;
     uint32_t width, height; // viewport of renderer.rs:107-108
-    uint32_t fan_cap;       // capacity of the fan region (triangles)
+    uint32_t fan_cap;       // capacity of the fan space (triangles): FAN_REGIONS regions of fan_cap / FAN_REGIONS (a multiple of FAN_REGIONS)
     int32_t reset_frame;    // first draw after frr_clear: the bookkeeping thread zeroes the frame counters first
     int32_t part_rank, part_world; // tile-row ownership filter (world == 1: none); only set by frr_draw,
     int32_t part_y0, part_y1;      // which knows the raster window's height range
@@ -156,6 +165,33 @@ __device__ __forceinline__ int local_tile_row(int ty, int rank, int world, int r
     if (world <= 1) return ty;
     if (rpr > 0) return ty - rank * rpr;
     return (int)(((float)ty + 0.5f) * (1.0f / (float)world)); // ty / world: exact for tile rows (< 2^11)
+}
+
+// The slots of the current draw as ONE virtual index range [0, total): the inputs' own slots, then the used part of fan
+// region 0, of region 1, ...  (what the binning kernels walk and split into chunks).
+struct FanMap { uint32_t ntris, region, pre[FAN_REGIONS + 1]; };   // pre[k]: used fan slots of the regions before k
+__device__ __forceinline__ FanMap fan_map(const Counters *cnt, int fslot, uint32_t fan_cap)
+{
+    FanMap m;
+    m.ntris = cnt->ntris_draw;
+    m.region = fan_cap / FAN_REGIONS;
+    m.pre[0] = 0u;
+#pragma unroll
+    for (int k = 0; k < FAN_REGIONS; ++k) m.pre[k + 1] = m.pre[k] + min(cnt->fan_cursor[fslot][k].v, m.region);
+    return m;
+}
+__device__ __forceinline__ uint32_t fan_map_total(const FanMap &m) { return m.ntris + m.pre[FAN_REGIONS]; }
+__device__ __forceinline__ uint32_t fan_map_slot(const FanMap &m, uint32_t v)
+{
+    if (v < m.ntris) return v;
+    const uint32_t u = v - m.ntris;
+    uint32_t k = 0;
+#pragma unroll
+    for (int j = 1; j < FAN_REGIONS; ++j) k += u >= m.pre[j] ? 1u : 0u;
+    uint32_t pk = 0;
+#pragma unroll
+    for (int j = 1; j < FAN_REGIONS; ++j) pk = k >= (uint32_t)j ? m.pre[j] : pk;
+    return m.ntris + k * m.region + (u - pk);
 }
 
 // what frr_clear does to the counters (by k_clear, or deferred to the next draw's bookkeeping thread)

@@ -116,13 +116,11 @@ struct PutMixed {
     }
 };
 
-// One binning record per lane (pb = the lane's pbox entry, all zero = nothing; the lanes of a wave hold the consecutive
-// slots base .. base+63): count it (SCATTER = false) or place it (true) in every owned tile its clamped bbox touches.
+// One binning record per lane (pb = the pbox entry of the lane's slot i, all zero = nothing): count it (SCATTER = false) or place it (true) in every owned tile its clamped bbox touches.
 // Called by whole waves: large footprints are spread over the lanes.
 template <bool SCATTER, class PUT>
-__device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, const uint4 pb, uint32_t base, int lane, const PUT &put)
+__device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, const uint4 pb, uint32_t i, int lane, const PUT &put)
 {
-    const uint32_t i = base + (uint32_t)lane;
     const TileRange t = tiles_of_pbox(a, pb);
     const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
     const int nt = ntx * nty;
@@ -177,7 +175,7 @@ __device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, c
         const uint32_t o1 = __shfl((uint32_t)ntx | ((uint32_t)nty << 16), sl);
         const int bx0 = (int)(o0 & 0xFFFFu), by0 = (int)(o0 >> 16), bnx = (int)(o1 & 0xFFFFu);
         const int bnt = src < 0 ? 0 : bnx * (int)(o1 >> 16);
-        const uint4 ent = make_uint4(base + sl, __shfl(pb.z, sl), __shfl(pb.x, sl), __shfl(pb.y, sl));
+        const uint4 ent = make_uint4(__shfl(i, sl), __shfl(pb.z, sl), __shfl(pb.x, sl), __shfl(pb.y, sl));
         // q -> (q % bnx, q / bnx) through a 1-ulp reciprocal: (q + 0.5) / bnx is at least 0.5 / bnx away from an integer
         const float inv = __builtin_amdgcn_rcpf((float)bnx);
         for (int q = lane & 15; q < bnt; q += 16) {
@@ -190,33 +188,36 @@ __device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, c
 // The slots [lo, hi) of `pbox`, by the waves of a BIN_WG-thread workgroup: a wave takes 64 consecutive slots per round,
 // BIN_PF rounds at a time -- their bboxes are fetched up front (the loop is latency-bound otherwise).
 constexpr int BIN_PF = 4;
-__device__ __forceinline__ void bin_load(const uint4 *__restrict__ pbox, uint32_t base0, uint32_t hi, int lane, uint4 (&pb)[BIN_PF])
+// (indices are VIRTUAL: FanMap turns them into slots; a wave whose 64 indices are all inputs' own slots skips the mapping)
+__device__ __forceinline__ void bin_load(const FanMap &fm, const uint4 *__restrict__ pbox, uint32_t base0, uint32_t hi, int lane,
+                                         uint4 (&pb)[BIN_PF], uint32_t (&id)[BIN_PF])
 {
 #pragma unroll
     for (int k = 0; k < BIN_PF; ++k) {
-        const uint32_t i = base0 + k * BIN_WG + lane;
-        pb[k] = i < hi ? pbox[i] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
+        const uint32_t v = base0 + k * BIN_WG + lane;
+        id[k] = base0 + k * BIN_WG + 64u <= fm.ntris ? v : fan_map_slot(fm, v);
+        pb[k] = v < hi ? pbox[id[k]] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
     }
 }
 template <bool SCATTER, class PUT>
-__device__ __forceinline__ void bin_rounds(const RasterArgs &a, uint32_t *s_hist, const uint4 (&pb)[BIN_PF], uint32_t base0, uint32_t hi,
-                                           int lane, const PUT &put)
+__device__ __forceinline__ void bin_rounds(const RasterArgs &a, uint32_t *s_hist, const uint4 (&pb)[BIN_PF], const uint32_t (&id)[BIN_PF],
+                                           uint32_t base0, uint32_t hi, int lane, const PUT &put)
 {
 #pragma unroll
     for (int k = 0; k < BIN_PF; ++k) {
-        const uint32_t base = base0 + k * BIN_WG;
-        if (base >= hi) break;
-        bin_one<SCATTER>(a, s_hist, pb[k], base, lane, put);
+        if (base0 + k * BIN_WG >= hi) break;
+        bin_one<SCATTER>(a, s_hist, pb[k], id[k], lane, put);
     }
 }
 template <bool SCATTER, class PUT>
-__device__ __forceinline__ void bin_walk(const RasterArgs &a, uint32_t *s_hist, const uint4 *__restrict__ pbox, uint32_t lo, uint32_t hi,
-                                         int lane, uint32_t wave, const PUT &put)
+__device__ __forceinline__ void bin_walk(const RasterArgs &a, uint32_t *s_hist, const FanMap &fm, const uint4 *__restrict__ pbox,
+                                         uint32_t lo, uint32_t hi, int lane, uint32_t wave, const PUT &put)
 {
     for (uint32_t base0 = lo + wave * 64u; base0 < hi; base0 += BIN_PF * BIN_WG) {
         uint4 pb[BIN_PF];
-        bin_load(pbox, base0, hi, lane, pb);
-        bin_rounds<SCATTER>(a, s_hist, pb, base0, hi, lane, put);
+        uint32_t id[BIN_PF];
+        bin_load(fm, pbox, base0, hi, lane, pb, id);
+        bin_rounds<SCATTER>(a, s_hist, pb, id, base0, hi, lane, put);
     }
 }
 
@@ -461,7 +462,8 @@ __device__ __forceinline__ void geom_bookkeeping(const GeomArgs &g)
     if (g.reset_frame) reset_frame_counters(cnt);
     cnt->tri_base += cnt->n_emit;          // the previous draw's triangles precede this draw's (its block sums are scanned by now)
     cnt->n_emit = 0u;
-    cnt->fan_cursor[g.fslot ^ 1] = 0u;
+#pragma unroll
+    for (int k = 0; k < FAN_REGIONS; ++k) cnt->fan_cursor[g.fslot ^ 1][k].v = 0u;
     cnt->clip_q[g.fslot ^ 1] = 0u; cnt->clip_block_max[g.fslot ^ 1] = 0u;
     cnt->ntris_draw = g.ntris;
     cnt->tinfo = g.tinfo; cnt->fanbase = g.fanbase; cnt->fan_okey = g.fan_okey; cnt->block_prefix = g.block_sums;
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     uint32_t fbase_pending = 0u;
     if (threadIdx.x == 0) {
         g.block_sums[bid] = total;
-        if (ftotal) fbase_pending = atomicAdd(&g.cnt->fan_cursor[g.fslot], ftotal);
+        if (ftotal) fbase_pending = atomicAdd(&g.cnt->fan_cursor[g.fslot][bid % FAN_REGIONS].v, ftotal);   // (within the block's region)
     }
     if (t < g.ntris) g.tinfo[t] = n | (eoff << FAN_BITS);
     if (clipped) s_cl[atomicAdd(&s_ncl, 1u)] = threadIdx.x | (foff << 8);
@@ -588,8 +590,9 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     // the block's clipped inputs, one wave per triangle (lanes = candidate vertices)
     if (threadIdx.x == 0) s_fbase = fbase_pending;
     __syncthreads();
-    const uint32_t fbase = s_fbase;
-    const bool fans_ok = fbase + ftotal <= g.fan_cap;  // else the frame is flagged invalid by geom_scan (cursor > capacity) and re-issued
+    const uint32_t fregion = g.fan_cap / FAN_REGIONS;
+    const bool fans_ok = s_fbase + ftotal <= fregion;  // else the frame is flagged invalid by geom_scan (a cursor > its region) and re-issued
+    const uint32_t fbase = (bid % FAN_REGIONS) * fregion + s_fbase;   // first fan slot of the block, relative to ntris
     if (clipped) g.fanbase[t] = fbase + foff;
     const uint32_t ncl = fans_ok ? s_ncl : 0u;
     if (ncl) {
@@ -666,9 +669,12 @@ __device__ __forceinline__ void geom_scan(uint32_t *sums, uint32_t nblocks, Coun
     }
     if (threadIdx.x == 0) {
         cnt->n_emit = s_carry;
-        const uint32_t fans = __hip_atomic_load(&cnt->fan_cursor[fslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cnt->need_fans = fans;
-        if (fans > fan_cap) atomicOr(&cnt->overflow, 1u);
+        uint32_t fans = 0;   // the fullest region decides: every region has fan_cap / FAN_REGIONS slots
+#pragma unroll
+        for (int k = 0; k < FAN_REGIONS; ++k)
+            fans = max(fans, __hip_atomic_load(&cnt->fan_cursor[fslot][k].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        cnt->need_fans = fans * FAN_REGIONS;
+        if (fans > fan_cap / FAN_REGIONS) atomicOr(&cnt->overflow, 1u);
     }
 }
 __global__ __launch_bounds__(1024) void k_geom_scan(uint32_t *sums, uint32_t nblocks, Counters *cnt, int fslot, uint32_t fan_cap)
@@ -683,22 +689,17 @@ __global__ __launch_bounds__(1024) void k_geom_scan(uint32_t *sums, uint32_t nbl
 // ---------------------------------------------------------------------------------------------
 constexpr int BIN_COOP = 6;
 
-// slots of the current draw to walk: the inputs' own slots and the fan slots handed out (frr_device.h)
-__device__ __forceinline__ uint32_t draw_slots(const Counters *cnt, int fslot, uint32_t fan_cap)
-{
-    return cnt->ntris_draw + min(cnt->fan_cursor[fslot], fan_cap);
-}
-
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(RasterArgs a, int fslot, uint32_t fan_cap)
 {
-    const uint32_t n = draw_slots(a.cnt, fslot, fan_cap);
+    const FanMap fm = fan_map(a.cnt, fslot, fan_cap);
+    const uint32_t n = fan_map_total(fm);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * 4u;
     for (uint32_t base = wave * 64u; base < n; base += nwaves * 64u) {
-        const uint32_t i = base + lane;
-        const uint4 cu = i < n ? a.pbox[i] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
+        const uint32_t i = fan_map_slot(fm, base + lane);   // (virtual index -> slot)
+        const uint4 cu = base + lane < n ? a.pbox[i] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
         const TileRange t = tiles_of_pbox(a, cu);
         const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
         const int nt = ntx * nty;
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(256) void k_bin(RasterArgs a, int fslot, uint32_t f
             const int src = __builtin_ctzll(big);
             big &= big - 1;
             const int bx0 = __shfl(t.tx0, src), by0 = __shfl(t.ty0, src), bnx = __shfl(ntx, src), bnt = __shfl(nt, src);
-            const uint4 ent = make_uint4(base + src, __shfl(cu.z, src), __shfl(cu.x, src), __shfl(cu.y, src));
+            const uint4 ent = make_uint4(__shfl(i, src), __shfl(cu.z, src), __shfl(cu.x, src), __shfl(cu.y, src));
             for (int k = lane; k < bnt; k += 64) visit(ent, bx0 + k % bnx, by0 + k / bnx);
         }
     }
@@ -789,7 +790,8 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     for (uint32_t t = threadIdx.x; t < ((ntiles + 3u) & ~3u); t += BIN_WG) s_hist[t] = 0u;   // (padded to four: bin_scan_relative)
     if (g == 0 && threadIdx.x == 0) bin_bookkeeping(a.cnt, slot);
     __syncthreads();
-    const uint32_t n = draw_slots(a.cnt, fslot, fan_cap);
+    const FanMap fm = fan_map(a.cnt, fslot, fan_cap);
+    const uint32_t n = fan_map_total(fm);
     uint32_t chunk = (n + G - 1) / G;
     chunk = (chunk + 63u) & ~63u;
     const uint32_t lo = min(n, g * chunk), hi = min(n, lo + chunk);
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
 #endif
     // (keeping the chunk's bboxes in registers from the counting walk to the placing walk saved nothing: the second read
     // comes from L2 and the 16 extra registers cost the 4096^2 frame 2 us)
-    bin_walk<false>(a, s_hist, a.pbox, lo, hi, lane, wave, PutNone{});
+    bin_walk<false>(a, s_hist, fm, a.pbox, lo, hi, lane, wave, PutNone{});
     __syncthreads();
 #ifdef FRR_DEBUG_COUNTERS
     const unsigned long long d_t1 = __builtin_amdgcn_s_memrealtime();
@@ -818,10 +820,10 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
         if (threadIdx.x == 0) s_base = bin_region_of(a, before, total);
         __syncthreads();
         base = s_base;
-        bin_walk<true>(a, s_hist, a.pbox, lo, hi, lane, wave, PutMixed{s_stage, a.bins, base, stage_cap, a.bin_cap});
+        bin_walk<true>(a, s_hist, fm, a.pbox, lo, hi, lane, wave, PutMixed{s_stage, a.bins, base, stage_cap, a.bin_cap});
         __syncthreads();
     } else {
-        bin_walk<true>(a, s_hist, a.pbox, lo, hi, lane, wave, PutStaged{s_stage});
+        bin_walk<true>(a, s_hist, fm, a.pbox, lo, hi, lane, wave, PutStaged{s_stage});
         if (threadIdx.x == 0) s_base = bin_region_of(a, before, total);
         __syncthreads();
         base = s_base;
