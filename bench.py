@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--workload", default="random_1M_tris_1920x1080_depth", choices=sorted(WORKLOADS) + sorted(ALIASES))
     ap.add_argument("--also", default="cfg4,cfg5",
                     help="comma-separated further workloads reported under 'secondary' (fewer steps each); 'none' disables")
+    ap.add_argument("--in-flight", action="store_true",
+                    help="N = 1 only: also time two contexts on two streams rendering alternate frames (extra key "
+                         "two_frames_in_flight; off by default so that a kernel trace of the default command holds "
+                         "one-frame-at-a-time launches only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="dev: initialise RCCL and run the slab gather even with one rank (exercises the N>1 code path)")
     ap.add_argument("--sync-gather", action="store_true",
@@ -475,7 +479,7 @@ def main():
             line["speedup_vs_cpu_1core"] = round(line["value"] / cpu["value"], 1)
             f_pass, n_setup = oc["frag_zpass"], oc["tris_setup"]
         run.roofline(line, f_pass, n_setup)
-    if rank == 0 and world == 1 and dist is None:
+    if rank == 0 and world == 1 and dist is None and args.in_flight:
         extra = two_frames_in_flight(torch, run, args.steps)
         if extra:
             line["two_frames_in_flight"] = extra

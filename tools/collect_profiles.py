@@ -8,6 +8,7 @@ TAG = "r02"
 one = lambda pat: sorted(glob.glob(os.path.join(F, pat)))[-1]
 shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"{TAG}_bench.json"))
 shutil.copy(os.path.join(F, "configs.json"), os.path.join(P, f"{TAG}_configs.json"))
+shutil.copy(os.path.join(F, "bench_in_flight.json"), os.path.join(P, f"{TAG}_bench_in_flight.json"))
 shutil.copy(os.path.join(F, "partition_times.json"), os.path.join(P, f"{TAG}_partition_times.json"))
 shutil.copy(os.path.join(F, "shapes.log"), os.path.join(P, f"{TAG}_tile_kernel_shapes.txt"))
 WL = {"headline": "random_1M_tris_1920x1080_depth", "cfg4": "random_1M_tris_4096x4096_depth", "cfg5": "sheets_259k_tris_3840x2160_blinn"}

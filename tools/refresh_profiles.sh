@@ -6,6 +6,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/final2; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
+python bench.py --in-flight --also none --cpu-baseline-seconds 0 > $O/bench_in_flight.json 2>> $O/bench.err || exit 1
 for w in headline cfg4 cfg5; do
   rocprofv3 --kernel-trace --stats -d $O/kt_$w --output-format csv -- python3 bench.py --workload $w --also none --steps 20 --warmup 3 --cpu-baseline-seconds 0 > $O/kt_$w.log 2>&1 || exit 1
   FRAMES=4 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_$w --output-format csv -- python3 tools/pmc_frame.py $w > $O/f_$w.log 2>&1 || exit 1
