@@ -497,10 +497,25 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
         for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
         n = classify(pos, clipped);
     }
+    // Multi-GPU: a clipped input is expanded (and gets fan slots) only where its fan can reach a tile row of this rank.
+    // The fan's vertices are the three originals and intersections a + r(b - a); with all w > 0 and no vertex beyond the
+    // near plane (whose ratio is the reference's a_w / (a_w - b_w), not a point of the edge: renderer.rs:70) every r is in
+    // [0, 1] up to rounding, so the fan's screen rows lie within the originals' rows -- widened by one for that rounding.
+    // Its triangle COUNT (n: ids of everything after it) is kept either way.
+    bool fan_here = clipped;
+    if (clipped && g.part_world > 1) {
+        const uint32_t in_all = inside_bits(pos[0]) & inside_bits(pos[1]) & inside_bits(pos[2]);
+        if ((in_all & 16u) && pos[0][3] > 0.0f && pos[1][3] > 0.0f && pos[2][3] > 0.0f) {
+            const float fw = (float)g.width, fh = (float)g.height;
+            const int y0 = clampi(to_screen(pos[0], fw, fh).iy, -(1 << 30), 1 << 30), y1 = clampi(to_screen(pos[1], fw, fh).iy, -(1 << 30), 1 << 30);
+            const int y2 = clampi(to_screen(pos[2], fw, fh).iy, -(1 << 30), 1 << 30);
+            fan_here = tri_rows_owned(g, min(y0, min(y1, y2)) - 1, max(y0, max(y1, y2)) + 1, y0);
+        }
+    }
     // ONE block scan for two prefix sums: emission offset within the block (low half) and fan slots of the clipped inputs
     // before this one (high half); an input emits at most 19 triangles, so a block's sums stay below 2^13
     uint32_t ptotal;
-    const uint32_t poff = block_excl_scan256(n | ((clipped ? n : 0u) << 16), s_w, ptotal);
+    const uint32_t poff = block_excl_scan256(n | ((fan_here ? n : 0u) << 16), s_w, ptotal);
     const uint32_t eoff = poff & 0xFFFFu, foff = poff >> 16, total = ptotal & 0xFFFFu, ftotal = ptotal >> 16;
     // ONE returning atomic per block that clips anything.  Device atomics on one address are served one after the other
     // (~17 ns each): when most blocks of a mesh clip something -- a mesh that crosses the frustum -- that is many
@@ -512,9 +527,9 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
         if (ftotal) fbase_pending = atomicAdd(&g.cnt->fan_cursor[g.fslot][bid % FAN_REGIONS].v, ftotal);   // (within the block's region)
     }
     if (t < g.ntris) g.tinfo[t] = n | (eoff << FAN_BITS);
-    if (clipped) s_cl[atomicAdd(&s_ncl, 1u)] = threadIdx.x | (foff << 8);
+    if (fan_here) s_cl[atomicAdd(&s_ncl, 1u)] = threadIdx.x | (foff << 8);
     // Multi-GPU: a rank that owns none of the tile rows an (unclipped) triangle's bbox touches never reads its record
-    // (geometry is replicated, so this is what keeps the replicated part small); clipped fans are kept on every rank
+    // (geometry is replicated, so this is what keeps the replicated part small)
     ScreenVtx s0 = {}, s1 = {}, s2 = {};
     bool emit = false;
     if (n == 1u && !clipped) {
@@ -593,7 +608,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     const uint32_t fregion = g.fan_cap / FAN_REGIONS;
     const bool fans_ok = s_fbase + ftotal <= fregion;  // else the frame is flagged invalid by geom_scan (a cursor > its region) and re-issued
     const uint32_t fbase = (bid % FAN_REGIONS) * fregion + s_fbase;   // first fan slot of the block, relative to ntris
-    if (clipped) g.fanbase[t] = fbase + foff;
+    if (fan_here) g.fanbase[t] = fbase + foff;
     const uint32_t ncl = fans_ok ? s_ncl : 0u;
     if (ncl) {
         // Meshes clip along lines that follow their index order (a grid sheet crossing a frustum plane: whole runs of

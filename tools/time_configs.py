@@ -1,6 +1,6 @@
 """Dev tool (GPU box): frame time and per-kernel time (HIP events) of the BASELINE configs with the library FRR_LIB points
 at (default: the in-tree build), plus an image hash -- for A/B runs of build variants.
-  [FRR_LIB=/path/lib.so] python tools/time_configs.py [headline cfg4 cfg5 cfg3 ...]"""
+  [FRR_LIB=/path/lib.so] [PART=rank,world] python tools/time_configs.py [headline cfg4 cfg5 cfg3 ...]"""
 import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import f_renderer_amd as fr
@@ -12,6 +12,9 @@ for name in (sys.argv[1:] or ["headline", "cfg4", "cfg5"]):
     W, H, mesh = cfg["W"], cfg["H"], cfg["mesh"]
     vs, ps = getattr(fr, "VS_" + cfg["vs"]), getattr(fr, "PS_" + cfg["ps"])
     r = fr.Renderer(W, H)
+    if os.environ.get("PART"):                       # PART=rank,world: one rank of the blocked tile partition
+        rank, world = (int(x) for x in os.environ["PART"].split(","))
+        r.set_partition(rank, world, blocked=True)
     if cfg["cam"]:
         eye, at, up, fovy, aspect, zn, zf = scenes.demo_camera(W, H)
         r.set_uniforms(view=fr.set_look_at(eye, at, up), proj=fr.set_perspective(fovy, aspect, zn, zf), view_pos=eye)
