@@ -73,6 +73,7 @@ struct frr_ctx {
     RasterRec *recs = nullptr; size_t setup_cap = 0;            // [input triangles + fan capacity]
     float *vary = nullptr; size_t vary_cap = 0; // floats
     uint4 *pbox = nullptr; size_t pbox_cap = 0;
+    uint32_t *bcount = nullptr; size_t bcount_cap = 0;          // [geometry blocks] dense binning entries per block (GeomArgs::bcount)
     uint2 *clipq = nullptr; size_t clipq_cap = 0;               // [input triangles] the clip kernel's queue (GeomArgs::clipq)
     int clip_queue = -1;        // option clip_queue: 1 use the queue + k_geom_clip, 0 never, -1 when the latest counters read back
     bool clip_queue_auto = false; //   showed a block with more than CLIP_QUEUE_AT clipped inputs (results are the same either way)
@@ -373,7 +374,7 @@ void frr_destroy(frr_ctx *c)
     prof_collect(c);
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
-    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->tinfo, c->fanbase, c->fan_okey, c->recs, c->vary, c->pbox, c->clipq,
+    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->tinfo, c->fanbase, c->fan_okey, c->recs, c->vary, c->pbox, c->bcount, c->clipq,
                     c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bins2, c->bin_matrix};
     for (void *p : ptrs) if (p) (void)hipFree(p);
 #ifdef FRR_DEBUG_COUNTERS
@@ -624,6 +625,7 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     if ((rc = ensure(c, c->fan_okey, c->fan_okey_cap, (size_t)std::max<uint64_t>(fan_cap, 1))) != FRR_OK) return rc;
     if ((rc = ensure(c, c->recs, c->setup_cap, std::max<size_t>(slots, 1024))) != FRR_OK) return rc;
     if ((rc = ensure(c, c->pbox, c->pbox_cap, c->setup_cap)) != FRR_OK) return rc;
+    if ((rc = ensure(c, c->bcount, c->bcount_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
     if (K > 0 && (rc = ensure(c, c->vary, c->vary_cap, (size_t)c->setup_cap * 3 * 8 /* K <= 8 in the shader table */)) != FRR_OK) return rc;
     const bool use_clipq = nt > 0 && (c->clip_queue > 0 || (c->clip_queue < 0 && c->clip_queue_auto));
     if (use_clipq && (rc = ensure(c, c->clipq, c->clipq_cap, (size_t)nt)) != FRR_OK) return rc;
@@ -644,6 +646,7 @@ static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filte
     g.block_sums = c->block_sums; g.tinfo = c->tinfo; g.fanbase = c->fanbase; g.fan_okey = c->fan_okey;
     g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;
     g.clipq = c->clipq; g.use_clipq = use_clipq ? 1 : 0;
+    g.bcount = c->bcount;
     // what the setup list about to be built was filtered by (frr_raster / frr_readback_setup check it)
     c->geom_filter = frr_ctx::GeomFilter{filter, fy0, fy1, c->rank, c->world, c->part_blocked};
     c->geom_slot = slot;
@@ -706,7 +709,7 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
     a.tiles_x_magic = 0u; // set below once the grid is known (exact only for block indices and tile counts < 2^16)
     a.rank = c->rank; a.world = c->world;
     a.rpr = (c->part_blocked && c->world > 1) ? std::max(1, (a.tiles_y + c->world - 1) / c->world) : 0;
-    a.recs = c->recs; a.vary = c->vary; a.pbox = c->pbox;
+    a.recs = c->recs; a.vary = c->vary; a.pbox = c->pbox; a.bcount = c->bcount;
     a.tile_counts = c->tile_counts; a.tile_offsets = c->tile_offsets; a.tile_cursor = c->tile_cursor;
     const uint32_t ntiles = (uint32_t)a.tiles_x * a.tiles_y;
     int rc;

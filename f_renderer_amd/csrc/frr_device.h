@@ -112,7 +112,11 @@ struct GeomArgs {
     float *vary;            // [ntris + fan_cap][3][K]
     uint2 *clipq;           // use_clipq: {input triangle, its first fan slot} of the clipped inputs a block does not expand itself
     int32_t use_clipq;      //   (k_geom_clip expands them, one wavefront each, balanced over the chip); 0: every block expands all of its own
-    uint4 *pbox;            // per slot, the binning input: {minx|miny<<16, maxx|maxy<<16 (i16 pixel bbox of spi), zkey of an upper bound of |rhw|, 0}; all zero = nothing here
+    uint4 *pbox;            // the binning input, 16 bytes per entry: {minx|miny<<16, maxx|maxy<<16 (i16 pixel bbox of spi), zkey of an
+                            // upper bound of |rhw|, slot}.  Inputs: block b's triangles that are set up here (unclipped, and on a
+                            // partitioned ctx touching a tile row of the rank) are the first bcount[b] entries of [256 b, 256 b + 256),
+                            // the rest of that range is zero (= an empty box); fan triangle at fan slot f: entry ntris + f
+    uint32_t *bcount;       // [nblocks] see pbox
     Counters *cnt;
 };
 
@@ -127,6 +131,7 @@ struct RasterArgs {
     const RasterRec *recs;
     const float *vary;
     const uint4 *pbox;                // see GeomArgs::pbox
+    const uint32_t *bcount;           // see GeomArgs::bcount
     uint32_t *tile_counts;            // [ntiles]
     uint32_t *tile_offsets;           // [ntiles+1]
     uint32_t *tile_cursor;            // [ntiles]

@@ -116,11 +116,12 @@ struct PutMixed {
     }
 };
 
-// One binning record per lane (pb = the pbox entry of the lane's slot i, all zero = nothing): count it (SCATTER = false) or place it (true) in every owned tile its clamped bbox touches.
+// One binning record per lane (pb = a pbox entry, all zero = nothing): count it (SCATTER = false) or place it (true) in every owned tile its clamped bbox touches.
 // Called by whole waves: large footprints are spread over the lanes.
 template <bool SCATTER, class PUT>
-__device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, const uint4 pb, uint32_t i, int lane, const PUT &put)
+__device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, const uint4 pb, int lane, const PUT &put)
 {
+    const uint32_t i = pb.w;    // the slot the entry stands for
     const TileRange t = tiles_of_pbox(a, pb);
     const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
     const int nt = ntx * nty;
@@ -185,39 +186,78 @@ __device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, c
     }
 }
 
-// The slots [lo, hi) of `pbox`, by the waves of a BIN_WG-thread workgroup: a wave takes 64 consecutive slots per round,
-// BIN_PF rounds at a time -- their bboxes are fetched up front (the loop is latency-bound otherwise).
+// The fan entries with VIRTUAL indices [lo, hi) (FanMap: the used parts of the fan regions laid end to end; index ntris
+// + ... ), by the waves of a BIN_WG-thread workgroup: a wave takes 64 consecutive ones per round, BIN_PF rounds at a time --
+// their bboxes are fetched up front (the loop is latency-bound otherwise).
 constexpr int BIN_PF = 4;
-// (indices are VIRTUAL: FanMap turns them into slots; a wave whose 64 indices are all inputs' own slots skips the mapping)
-__device__ __forceinline__ void bin_load(const FanMap &fm, const uint4 *__restrict__ pbox, uint32_t base0, uint32_t hi, int lane,
-                                         uint4 (&pb)[BIN_PF], uint32_t (&id)[BIN_PF])
-{
-#pragma unroll
-    for (int k = 0; k < BIN_PF; ++k) {
-        const uint32_t v = base0 + k * BIN_WG + lane;
-        id[k] = base0 + k * BIN_WG + 64u <= fm.ntris ? v : fan_map_slot(fm, v);
-        pb[k] = v < hi ? pbox[id[k]] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
-    }
-}
 template <bool SCATTER, class PUT>
-__device__ __forceinline__ void bin_rounds(const RasterArgs &a, uint32_t *s_hist, const uint4 (&pb)[BIN_PF], const uint32_t (&id)[BIN_PF],
-                                           uint32_t base0, uint32_t hi, int lane, const PUT &put)
-{
-#pragma unroll
-    for (int k = 0; k < BIN_PF; ++k) {
-        if (base0 + k * BIN_WG >= hi) break;
-        bin_one<SCATTER>(a, s_hist, pb[k], id[k], lane, put);
-    }
-}
-template <bool SCATTER, class PUT>
-__device__ __forceinline__ void bin_walk(const RasterArgs &a, uint32_t *s_hist, const FanMap &fm, const uint4 *__restrict__ pbox,
-                                         uint32_t lo, uint32_t hi, int lane, uint32_t wave, const PUT &put)
+__device__ __forceinline__ void bin_walk_fans(const RasterArgs &a, uint32_t *s_hist, const FanMap &fm, const uint4 *__restrict__ pbox,
+                                              uint32_t lo, uint32_t hi, int lane, uint32_t wave, const PUT &put)
 {
     for (uint32_t base0 = lo + wave * 64u; base0 < hi; base0 += BIN_PF * BIN_WG) {
         uint4 pb[BIN_PF];
-        uint32_t id[BIN_PF];
-        bin_load(fm, pbox, base0, hi, lane, pb, id);
-        bin_rounds<SCATTER>(a, s_hist, pb, id, base0, hi, lane, put);
+#pragma unroll
+        for (int k = 0; k < BIN_PF; ++k) {
+            const uint32_t v = base0 + k * BIN_WG + lane;
+            pb[k] = v < hi ? pbox[fan_map_slot(fm, v)] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
+        }
+#pragma unroll
+        for (int k = 0; k < BIN_PF; ++k) {
+            if (base0 + k * BIN_WG >= hi) break;
+            bin_one<SCATTER>(a, s_hist, pb[k], lane, put);
+        }
+    }
+}
+// The inputs of the geometry blocks [b_lo, b_hi).  A block's entries are dense from the start of its 256-entry range
+// (GeomArgs::pbox), so only the 64-entry quarters below its count exist -- a rank of an 8-way partition walks an eighth of
+// what the whole window walks.  The existing quarters of 64 blocks at a time are numbered by a prefix sum over the blocks'
+// counts (every wave computes it: one load per lane and a DPP scan) and dealt to the waves round-robin, BIN_PF per wave
+// and step, their bboxes fetched together.
+template <bool SCATTER, class PUT>
+__device__ __forceinline__ void bin_walk_blocks(const RasterArgs &a, uint32_t *s_hist, const uint4 *__restrict__ pbox,
+                                                const uint32_t *__restrict__ bcount, uint32_t ntris, uint32_t b_lo, uint32_t b_hi,
+                                                int lane, uint32_t wave, const PUT &put)
+{
+    if (a.world <= 1) {
+        // the whole window: nearly every quarter exists, so they are taken as they come, without looking at the counts
+        // (entries past a block's count are zero: an empty box)
+        const uint32_t nq = (b_hi - b_lo) * (GEOM_BLOCK / 64);
+        for (uint32_t q0 = wave; q0 < nq; q0 += BIN_PF * (BIN_WG / 64)) {
+            uint4 pb[BIN_PF];
+#pragma unroll
+            for (int k = 0; k < BIN_PF; ++k) {
+                const uint32_t q = q0 + k * (BIN_WG / 64);
+                const uint32_t e = b_lo * GEOM_BLOCK + q * 64u + (uint32_t)lane;   // (the last block ends at ntris: fan entries follow)
+                pb[k] = q < nq && e < ntris ? pbox[e] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < BIN_PF; ++k)
+                if (q0 + k * (BIN_WG / 64) < nq) bin_one<SCATTER>(a, s_hist, pb[k], lane, put);
+        }
+        return;
+    }
+    for (uint32_t bb = b_lo; bb < b_hi; bb += 64u) {
+        const uint32_t c_l = bb + (uint32_t)lane < b_hi ? bcount[bb + lane] : 0u;
+        const uint32_t incl = wave_incl_scan_dpp((c_l + 63u) >> 6);           // quarters of the blocks up to and including this lane's
+        const uint32_t U = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        for (uint32_t u0 = wave; u0 < U; u0 += BIN_PF * (BIN_WG / 64)) {
+            uint4 pb[BIN_PF];
+#pragma unroll
+            for (int k = 0; k < BIN_PF; ++k) {
+                const uint32_t u = u0 + k * (BIN_WG / 64);                    // wave-uniform
+                pb[k] = make_uint4(0u, 0u, 0u, 0u);
+                if (u < U) {
+                    const int blk = __popcll(__ballot(incl <= u));            // the block quarter u belongs to (lanes past the range hold U)
+                    const uint32_t before = blk ? (uint32_t)__builtin_amdgcn_readlane((int)incl, blk - 1) : 0u;
+                    const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)c_l, blk);
+                    const uint32_t e = (u - before) * 64u + (uint32_t)lane;   // entry within the block
+                    if (e < cb) pb[k] = pbox[(size_t)(bb + blk) * GEOM_BLOCK + e];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < BIN_PF; ++k)
+                if (u0 + k * (BIN_WG / 64) < U) bin_one<SCATTER>(a, s_hist, pb[k], lane, put);
+        }
     }
 }
 
@@ -356,7 +396,7 @@ __device__ __forceinline__ uint4 clip_triangle_wave(const GeomArgs &g, const Dev
         const uint32_t fslot = fbase + (uint32_t)q;             // fan triangle q of input t: emission order is q order
         const uint32_t idx = g.ntris + fslot;
         g.fan_okey[fslot] = (t << FAN_BITS) + 1u + (uint32_t)q;
-        { const uint2 pb = pack_pbox(p0x, p0y, p1x, p1y, p2x, p2y); mine = make_uint4(pb.x, pb.y, cull_zub(v0[0], v1[0], v2[0]), 0u); g.pbox[idx] = mine; }
+        { const uint2 pb = pack_pbox(p0x, p0y, p1x, p1y, p2x, p2y); mine = make_uint4(pb.x, pb.y, cull_zub(v0[0], v1[0], v2[0]), idx); g.pbox[idx] = mine; }
         uint4 *dst = reinterpret_cast<uint4 *>(g.recs + idx);
         dst[0] = make_uint4((uint32_t)p0x, (uint32_t)p0y, (uint32_t)p1x, (uint32_t)p1y);
         dst[1] = make_uint4((uint32_t)p2x, (uint32_t)p2y, f2u(v0[3]), f2u(v0[4]));
@@ -482,6 +522,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     __shared__ uint32_t s_cl[GEOM_BLOCK];                 // the block's clipped inputs: thread | fan offset within the block << 8
     __shared__ uint32_t s_slot[GEOM_BLOCK / 64][64];      // per wave: the slot of the k-th lane that stores a record (when they are not a run)
     __shared__ uint32_t s_ncl, s_fbase;
+    __shared__ uint32_t s_wown[GEOM_BLOCK / 64];          // per wave: triangles it sets up (the block's dense binning entries)
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K;
     const uint32_t bid = blockIdx.x;
     const uint32_t t = bid * GEOM_BLOCK + threadIdx.x;
@@ -537,10 +578,21 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
         s0 = to_screen(pos[0], fw, fh); s1 = to_screen(pos[1], fw, fh); s2 = to_screen(pos[2], fw, fh);
         emit = tri_rows_owned(g, s0.iy, s1.iy, s2.iy);
     }
-    if (t < g.ntris && !emit) g.pbox[t] = make_uint4(0u, 0u, 0u, 0u); // nothing at slot t (dropped / clipped / not this rank's)
+    // the block's binning entries: dense from the start of its range, zero behind them (GeomArgs::pbox)
+    const unsigned long long own_m = __ballot(emit);
+    if ((threadIdx.x & 63) == 0) s_wown[threadIdx.x >> 6] = (uint32_t)__popcll(own_m);
+    __syncthreads();
+    uint32_t own_base = 0, own_total = 0;
+#pragma unroll
+    for (int k = 0; k < GEOM_BLOCK / 64; ++k) { const uint32_t x = s_wown[k]; if (k < (int)(threadIdx.x >> 6)) own_base += x; own_total += x; }
+    if (threadIdx.x == 0) g.bcount[bid] = own_total;
+    if (threadIdx.x >= own_total && t < g.ntris) g.pbox[t] = make_uint4(0u, 0u, 0u, 0u);
     if (emit) {
     const SetupOut so = setup_unclipped(pos, s0, s1, s2);
-    g.pbox[t] = so.pbox;
+    {
+        const uint32_t dense = own_base + __builtin_amdgcn_mbcnt_hi((uint32_t)(own_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)own_m, 0u));
+        g.pbox[bid * GEOM_BLOCK + dense] = make_uint4(so.pbox.x, so.pbox.y, so.pbox.z, t);
+    }
     const uint4 q0 = so.q0, q1 = so.q1, q2 = so.q2, q3 = so.q3;
     auto in_slot_f = [&](int sl, float x0, float x1, float x2) { return so.d0 == sl ? x0 : (so.d1 == sl ? x1 : x2); };
     const unsigned long long am = __ballot(true);
@@ -713,8 +765,9 @@ __global__ __launch_bounds__(256) void k_bin(RasterArgs a, int fslot, uint32_t f
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * 4u;
     for (uint32_t base = wave * 64u; base < n; base += nwaves * 64u) {
-        const uint32_t i = fan_map_slot(fm, base + lane);   // (virtual index -> slot)
-        const uint4 cu = base + lane < n ? a.pbox[i] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
+        // entry index: the inputs' entries (dense per block, zero = nothing, GeomArgs::pbox), then the used fan entries
+        const uint4 cu = base + lane < n ? a.pbox[fan_map_slot(fm, base + lane)] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
+        const uint32_t i = cu.w;   // the slot the entry stands for
         const TileRange t = tiles_of_pbox(a, cu);
         const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
         const int nt = ntx * nty;
@@ -805,11 +858,13 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     for (uint32_t t = threadIdx.x; t < ((ntiles + 3u) & ~3u); t += BIN_WG) s_hist[t] = 0u;   // (padded to four: bin_scan_relative)
     if (g == 0 && threadIdx.x == 0) bin_bookkeeping(a.cnt, slot);
     __syncthreads();
+    // a workgroup's chunk: a range of geometry blocks (their dense entries) and a range of the used fan entries
     const FanMap fm = fan_map(a.cnt, fslot, fan_cap);
-    const uint32_t n = fan_map_total(fm);
-    uint32_t chunk = (n + G - 1) / G;
-    chunk = (chunk + 63u) & ~63u;
-    const uint32_t lo = min(n, g * chunk), hi = min(n, lo + chunk);
+    const uint32_t bpw = (nblocks + G - 1) / G;
+    const uint32_t b_lo = min(nblocks, g * bpw), b_hi = min(nblocks, b_lo + bpw);
+    const uint32_t nfan = fm.pre[FAN_REGIONS];
+    const uint32_t fchunk = ((nfan + G - 1) / G + 63u) & ~63u;
+    const uint32_t lo = fm.ntris + min(nfan, g * fchunk), hi = fm.ntris + min(nfan, g * fchunk + fchunk);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef FRR_DEBUG_COUNTERS
@@ -817,7 +872,8 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
 #endif
     // (keeping the chunk's bboxes in registers from the counting walk to the placing walk saved nothing: the second read
     // comes from L2 and the 16 extra registers cost the 4096^2 frame 2 us)
-    bin_walk<false>(a, s_hist, fm, a.pbox, lo, hi, lane, wave, PutNone{});
+    bin_walk_blocks<false>(a, s_hist, a.pbox, a.bcount, fm.ntris, b_lo, b_hi, lane, wave, PutNone{});
+    bin_walk_fans<false>(a, s_hist, fm, a.pbox, lo, hi, lane, wave, PutNone{});
     __syncthreads();
 #ifdef FRR_DEBUG_COUNTERS
     const unsigned long long d_t1 = __builtin_amdgcn_s_memrealtime();
@@ -835,10 +891,14 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
         if (threadIdx.x == 0) s_base = bin_region_of(a, before, total);
         __syncthreads();
         base = s_base;
-        bin_walk<true>(a, s_hist, fm, a.pbox, lo, hi, lane, wave, PutMixed{s_stage, a.bins, base, stage_cap, a.bin_cap});
+        const PutMixed put{s_stage, a.bins, base, stage_cap, a.bin_cap};
+        bin_walk_blocks<true>(a, s_hist, a.pbox, a.bcount, fm.ntris, b_lo, b_hi, lane, wave, put);
+        bin_walk_fans<true>(a, s_hist, fm, a.pbox, lo, hi, lane, wave, put);
         __syncthreads();
     } else {
-        bin_walk<true>(a, s_hist, fm, a.pbox, lo, hi, lane, wave, PutStaged{s_stage});
+        const PutStaged put{s_stage};
+        bin_walk_blocks<true>(a, s_hist, a.pbox, a.bcount, fm.ntris, b_lo, b_hi, lane, wave, put);
+        bin_walk_fans<true>(a, s_hist, fm, a.pbox, lo, hi, lane, wave, put);
         if (threadIdx.x == 0) s_base = bin_region_of(a, before, total);
         __syncthreads();
         base = s_base;
