@@ -43,7 +43,7 @@ WORKLOADS = {
 }
 ALIASES = {cfg: name for name, (cfg, _) in WORKLOADS.items()}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROF_PERIOD = 4        # HIP events around the dominant kernel only, every 4th launch (a pair costs the stream ~4 us)
+PROF_PERIOD = 8             # k_raster launches are bracketed by HIP events only every 8th time (an event pair costs the stream ~4 us)
 
 
 def parse_args():
