@@ -302,3 +302,36 @@ def test_clip_queue_gives_the_same_setup_and_frame(oracle, monkeypatch, mode):
         g = r.setup_triangles()
         assert g.shape[0] == setup.shape[0]
         np.testing.assert_array_equal(g["ctx"][..., :8].view(np.uint32), setup["ctx"][..., :8].view(np.uint32))
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_binning_chunks_of_more_than_64_blocks(oracle, world):
+    """A binning workgroup walks its geometry blocks 64 at a time (bin_walk_blocks: the per-block counts of the dense
+    binning entries are scanned by one wave).  Two chunks over 60,000 triangles (118 blocks each; what a mesh of more than
+    16 M triangles does with 255 chunks), whole window and a 3-way partition stitched together: ids, depth and the setup
+    counts are the oracle's."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H = 400, 300
+    tris = scenes.random_clip_triangles(60000, W, H, seed=77, spread=1.2)
+    f = oracle.Frame(W, H)
+    f.clear()
+    f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
+    got_t = np.full(W * H, 0xFFFFFFFF, np.uint32)
+    got_d = np.zeros(W * H, np.float32)
+    for rank in range(world):
+        r = fr.Renderer(W, H)
+        r.set_option("bin_chunks", 2)
+        if world > 1:
+            r.set_partition(rank, world, blocked=True)
+        for _ in range(2):
+            r.clear()
+            r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
+        _, d, t = r.readback()
+        assert r.stats()["tris_setup"] == f.counters.tris_setup
+        for y0, y1 in (r.owned_rows((0, H)) if world > 1 else [(0, H)]):
+            got_t[y0 * W:y1 * W] = t[y0 * W:y1 * W]
+            got_d[y0 * W:y1 * W] = d[y0 * W:y1 * W]
+        r.close()
+    np.testing.assert_array_equal(got_t, f.tri_id)
+    np.testing.assert_array_equal(got_d.view(np.uint32), f.depth.view(np.uint32))
