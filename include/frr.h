@@ -209,7 +209,8 @@ int frr_set_option(frr_ctx *ctx, const char *name, int64_t value);
 /* per-kernel accumulated device time (ms) and launch count since frr_profile_reset.  `mask`:
  * 0 = off, -1 = every kernel, else OR of (1 << index) with index in the order k_clear,
  * k_geom, k_geom_scan, k_bin_count, k_tile_scan, k_bin_fill, k_raster,
- * k_bin_seg.  A profiled launch is bracketed by two HIP events on the ctx stream. */
+ * k_bin_seg (k_geom covers the clip kernel too when the clip queue is in use).  A profiled launch is bracketed by two
+ * HIP events on the ctx stream. */
 int frr_profile_enable(frr_ctx *ctx, int mask);
 /* bracket only every `period`-th launch of each selected kernel (default 1): an event pair costs the
  * stream ~4 us, which matters when the whole frame is 150 us; frr_profile_get then reports the sampled
