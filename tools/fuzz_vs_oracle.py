@@ -16,6 +16,9 @@ for it in range(N):
     tris = scenes.random_clip_triangles(n, W, H, seed=seed, spread=spread, w_jitter=wj)
     if rng.random() < 0.2:
         tris[:: max(1, n // 7), int(rng.integers(0, 3)), 3] = 0.0
+    if rng.random() < 0.2:                                   # vertices whose screen position overflows: fans of NaN-depth fragments
+        tris[:: max(1, n // 5), int(rng.integers(0, 3)), 0] = 3e38
+    opts = {"clip_queue": int(rng.integers(-1, 2)), "raster_nw": int(rng.choice([0, 0, 3, 4, 8, 16]))}
     f = cref.Frame(W, H); f.clear((3, 2, 1, 0), 0.0)
     f.draw(tris, cref.VS_CLIP, cref.PS_DEPTH, cref.make_uniforms())
     has_nan = bool(f.counters.frag_nan)   # (NaN depth fragments follow the reference's sequential rule: compared, NaN == NaN)
@@ -24,6 +27,7 @@ for it in range(N):
     acc_t = np.full(W * H, 0xFFFFFFFF, np.uint32); acc_d = np.zeros(W * H, np.float32); cov = 0
     for rank in range(G):
         r = fr.Renderer(W, H)
+        for k_, v_ in opts.items(): r.set_option(k_, v_)
         if G > 1: r.set_partition(rank, G, blocked=blocked)
         r.set_count_fragments(bool(rng.integers(0, 2)) or True)
         m = r.upload_mesh(tris, fr.VS_CLIP)
@@ -45,5 +49,5 @@ for it in range(N):
     if it % 10 == 0:
         print("case", it, "bad so far", bad, flush=True)
     if not ok:
-        bad += 1; print("MISMATCH", it, W, H, n, spread, wj, seed, G, blocked, flush=True)
+        bad += 1; print("MISMATCH", it, W, H, n, spread, wj, seed, G, blocked, opts, flush=True)
 print("fuzz done:", N, "cases,", nan_cases, "with NaN fragments,", bad, "bad")
