@@ -356,7 +356,7 @@ __device__ __forceinline__ ScreenVtx to_screen(const float pos[4], float fw, flo
     return v;
 }
 // Multi-GPU: does a (not clipped) triangle with snapped corner rows iy0..iy2 touch a tile row this rank owns?
-// (used identically by k_geom_count and k_geom_emit: the two must agree on every triangle)
+// (also asked, with the rows widened by one, for the fan of a clipped input: k_geom_single)
 __device__ __forceinline__ bool tri_rows_owned(const GeomArgs &g, int iy0, int iy1, int iy2)
 {
     if (g.part_world <= 1) return true;

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     // ONE returning atomic per block that clips anything.  Device atomics on one address are served one after the other
     // (~17 ns each): when most blocks of a mesh clip something -- a mesh that crosses the frustum -- that is many
     // microseconds of queueing, so the result is not waited for here: the block sets up and stores its unclipped
-    // triangles first (the 250,000-triangle sheets of the 4K frame: 44 -> ... us)
+    // triangles first (the 250,000-triangle sheets of the 4K frame, with the eight cursors: 41 -> 22 us)
     uint32_t fbase_pending = 0u;
     if (threadIdx.x == 0) {
         g.block_sums[bid] = total;
