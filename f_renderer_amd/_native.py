@@ -50,7 +50,7 @@ class SetupVertex(C.Structure):
 class Stats(C.Structure):
     _fields_ = [
         ("tris_in", C.c_uint64), ("tris_setup", C.c_uint64), ("bin_entries", C.c_uint64),
-        ("frag_covered", C.c_uint64), ("frag_nan", C.c_uint64), ("draws", C.c_uint32), ("overflow", C.c_uint32),
+        ("frag_covered", C.c_uint64), ("frag_nan", C.c_uint64), ("draws", C.c_uint32), ("replays", C.c_uint32),
     ]
 
     def as_dict(self):

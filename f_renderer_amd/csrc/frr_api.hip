@@ -32,65 +32,109 @@ struct Texture {
 };
 struct ProfRec { int kid; hipEvent_t a, b; };
 
+// Workspace of one geometry pass / one raster pass.  There are two of each, used alternately (parity of the pass), so
+// that the geometry + binning kernels of pass n + 1 can run on the ctx's second stream while the tile kernel of pass n
+// still reads what pass n left (frr_device.h: GeomTab / BinTab are the device-side halves of the same scheme).
+struct GeomSet {
+    uint32_t *block_sums = nullptr; size_t block_sums_cap = 0; // per 256-triangle block: triangles emitted
+    uint32_t *block_prefix = nullptr; size_t block_prefix_cap = 0; // ... and their exclusive scan
+    uint32_t *tinfo = nullptr; size_t tinfo_cap = 0;           // per input: fan size | emission offset in its block
+    uint32_t *fanbase = nullptr; size_t fanbase_cap = 0;       // per clipped input: first fan slot
+    uint32_t *fan_okey = nullptr; size_t fan_okey_cap = 0;     // per fan slot: order key within the draw
+    RasterRec *recs = nullptr; size_t setup_cap = 0;            // [input triangles + fan capacity]
+    float *vary = nullptr; size_t vary_cap = 0;                 // floats
+    uint4 *pbox = nullptr; size_t pbox_cap = 0;
+    uint32_t *bcount = nullptr; size_t bcount_cap = 0;          // [geometry blocks] dense binning entries per block (GeomArgs::bcount)
+    uint2 *clipq = nullptr; size_t clipq_cap = 0;               // [input triangles] the clip kernel's queue (GeomArgs::clipq)
+    uint64_t last_reader = 0;                                   // serial of the latest tile kernel that reads this set
+};
+struct BinSet {
+    uint4 *bins = nullptr; size_t bin_cap = 0;   // 16-byte cull records, one per (triangle, tile) pair
+    uint4 *bins2 = nullptr; size_t bin2_cap = 0; // the same in near-first order per tile (tile kernel pre-pass)
+    uint32_t *bin_matrix = nullptr; size_t bin_matrix_cap = 0; // [G][ntiles] per-chunk tile histograms
+    uint64_t last_reader = 0;
+};
+
+struct GeomFilter { bool active; int32_t y0, y1; int rank, world; bool blocked; };
+
+// Everything a command reads and changes on the host.  Every logged command carries the state it started from, so that
+// the commands from a failed one onwards can be replayed (finish()).
+struct FrameState {
+    uint8_t *color = nullptr; float *depth = nullptr; uint32_t *tri_id = nullptr; // the frame targets (own or caller-bound)
+    int rank = 0, world = 1; bool part_blocked = false;                           // tile-row ownership (frr_set_partition*)
+    // frr_clear is deferred: the first full-window draw of the span kernel performs it inside the tile kernel
+    // (keys start from the clear depth, every pixel of the tile is written); anything else that looks at the
+    // targets first settles it with k_clear.  option clear_eager restores the immediate clear.
+    bool clear_pending = false;    // targets not cleared yet
+    bool unowned_debt = false;     // partitioned ctx: the tile rows of other ranks missed a fused clear
+    int debt_tiles_y = 0;          //   (tile rows of the window of the draw that left the debt)
+    uint32_t clear_rgba = 0; float clear_depth = 0.0f;
+    uint32_t frame_no = 1;         // frr_clear count (device statistics are tagged with it)
+    uint64_t tris_in = 0; uint32_t draws = 0;   // statistics the host knows: inputs submitted / geometry passes since frr_clear
+    int gpar = 0, bpar = 0;        // parity of the latest geometry / raster pass (GeomSet / BinSet / GeomTab / BinTab)
+    GeomFilter geom_filter = {false, 0, 0, 0, 1, false}; // tile-row ownership filter the latest setup list was built with (frr_draw on a partitioned ctx)
+    uint32_t geom_fan_cap = 0;     // fan capacity the latest geometry pass was launched with
+    uint32_t geom_nblocks = 0;
+    uint32_t geom_seq = 0;         // its sequence number
+    bool scan_pending = false;     // its block sums are not scanned yet (geom_scan: by the binning launch, or k_geom_scan)
+    int geom_vs = -1;              // VS of the latest frr_geometry
+    uint64_t geom_ntris = 0;
+};
+
+struct Cmd {
+    enum Kind { GEOM, RASTER } kind;
+    FrameState pre;            // host state before the command
+    uint32_t seq = 0;          // sequence number of its latest execution
+    DevUniforms duni;          // uniforms at the time of the call
+    // GEOM
+    int mesh = -1; bool filter = false; int32_t fy0 = 0, fy1 = 0;
+    // RASTER
+    int ps = 0; int32_t x0 = 0, x1 = 0, y0 = 0, y1 = 0; bool count_frags = true;
+    int par = 0;               // the parity it ran with (finish(): which table a failed command left behind)
+};
+
 } // namespace
 
 struct frr_ctx {
     int device = 0;
     uint32_t W = 0, H = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // the caller's stream (or a private one): tile kernels, clears, copies -- everything that touches the targets
+    hipStream_t gstream = nullptr;  // private: geometry + binning of the next pass, beside the tile kernel of the current one
     bool own_stream = false;
-    uint8_t *color = nullptr, *own_color = nullptr;
-    float *depth = nullptr, *own_depth = nullptr;
-    uint32_t *tri_id = nullptr, *own_tri_id = nullptr;
+    bool overlap = true;            // option overlap: use gstream (else everything runs on `stream`)
+    uint8_t *own_color = nullptr; float *own_depth = nullptr; uint32_t *own_tri_id = nullptr;
     Counters *cnt = nullptr;
-    // geometry workspace (slots and order keys: frr_device.h)
-    uint32_t *block_sums = nullptr; size_t block_sums_cap = 0; // per 256-triangle block: triangles emitted; scanned in place
-    uint32_t *tinfo = nullptr; size_t tinfo_cap = 0;           // per input: fan size | emission offset in its block
-    uint32_t *fanbase = nullptr; size_t fanbase_cap = 0;       // per clipped input: first fan slot
-    uint32_t *fan_okey = nullptr; size_t fan_okey_cap = 0;     // per fan slot: order key within the draw
-    struct GeomFilter { bool active; int32_t y0, y1; int rank, world; bool blocked; };
-    GeomFilter geom_filter = {false, 0, 0, 0, 1, false}; // tile-row ownership filter the latest setup list was built with (frr_draw on a partitioned ctx)
-    int geom_slot = 0;         // Counters::fan_cursor slot of the latest draw (alternates per draw)
-    uint32_t geom_fan_cap = 0; // fan capacity the latest draw was launched with
-    uint32_t geom_nblocks = 0;
-    bool scan_pending = false; // the latest draw's block sums are not scanned yet (geom_scan: by the binning launch, or k_geom_scan)
+    FrameState fs;
+    GeomSet gset[2];
+    BinSet bset[2];
+    // cross-stream ordering: tile kernels are numbered; ev_tile[n & 3] fires when tile kernel n is done (the second
+    // stream waits for it before it overwrites a workspace that kernel reads), ev_bin[k & 3] when binning k is done
+    hipEvent_t ev_tile[4] = {}, ev_bin[4] = {}, ev_join = nullptr;
+    uint64_t tile_serial = 0, g_waited = 0, bin_serial = 0;
+    bool need_join = true;          // the second stream has not yet waited for what the caller put on `stream` (mesh data)
+    // command log since the last synchronisation point / frr_clear (finish(): replay)
+    std::vector<Cmd> log;
+    uint32_t next_seq = 1, epoch = 1;
+    uint32_t replays = 0;           // replays since frr_clear (frr_stats.replays)
+    bool in_replay = false;
+    Counters hc;                    // host copy of the device counters as of the latest finish()
     size_t fan_hint = 0;       // fan capacity asked for by a draw that overflowed
     int bin_g = 0;             // option bin_chunks: override the number of binning chunks (dev)
     uint32_t ent_slot_override = 0; // option tile_slot_records: per-tile slot of bins2 in records (tests of the overflow arena)
-    // frr_clear is deferred: the first full-window draw of the span kernel performs it inside the tile kernel
-    // (keys start from the clear depth, every pixel of the tile is written); anything else that looks at the
-    // targets or the counters first settles it with k_clear.  option clear_eager restores the immediate clear.
-    bool part_blocked = false;     // frr_set_partition_layout: contiguous blocks of tile rows instead of interleaved rows
     bool clear_eager = false;
-    bool clear_pending = false;    // targets not cleared yet
-    bool counters_pending = false; // frame counters not reset yet (the next draw's bookkeeping thread does it)
-    bool unowned_debt = false;     // partitioned ctx: the tile rows of other ranks missed a fused clear
-    int debt_rpr = 0;              //   (RasterArgs::rpr of the draw that left the debt)
-    uint32_t clear_rgba = 0; float clear_depth = 0.0f;
-    int bin_slot = 0;          // Counters::seg_total / ent_cursor slot of the latest draw (alternates)
     bool bin_atomics = false;  // option bin_atomics: force the global-atomic binning fallback (tests)
-    size_t bin_cap_init = 0;   // option bin_capacity: initial bin capacity in entries (tests of the overflow path)
-    RasterRec *recs = nullptr; size_t setup_cap = 0;            // [input triangles + fan capacity]
-    float *vary = nullptr; size_t vary_cap = 0; // floats
-    uint4 *pbox = nullptr; size_t pbox_cap = 0;
-    uint32_t *bcount = nullptr; size_t bcount_cap = 0;          // [geometry blocks] dense binning entries per block (GeomArgs::bcount)
-    uint2 *clipq = nullptr; size_t clipq_cap = 0;               // [input triangles] the clip kernel's queue (GeomArgs::clipq)
+    size_t bin_cap_init = 0;   // option bin_capacity: initial capacity of the (triangle, tile) lists in records (overflow / replay tests)
+    size_t fan_cap_init = 0;   // option fan_capacity: initial fan capacity (the same)
     int clip_queue = -1;        // option clip_queue: 1 use the queue + k_geom_clip, 0 never, -1 when the latest counters read back
     bool clip_queue_auto = false; //   showed a block with more than CLIP_QUEUE_AT clipped inputs (results are the same either way)
-    // binning workspace
+    // binning workspace of the CSR fallback (one set: that path does not overlap)
     uint32_t *tile_counts = nullptr, *tile_offsets = nullptr, *tile_cursor = nullptr;
     uint32_t max_tiles = 0;
-    uint4 *bins = nullptr; size_t bin_cap = 0;   // 16-byte cull records, one per (triangle, tile) pair
-    uint4 *bins2 = nullptr; size_t bin2_cap = 0; // the same in near-first order per tile (tile kernel pre-pass)
-    uint32_t *bin_matrix = nullptr; size_t bin_matrix_cap = 0; // [G][ntiles] per-chunk tile histograms
     bool lds_attr_set = false;
     std::vector<Mesh> meshes;
     Texture tex[FRR_MAX_TEXTURES];
     frr_uniforms uni;
     DevUniforms duni;
-    int geom_vs = -1;         // VS of the last frr_geometry
-    uint64_t geom_ntris = 0;
-    int rank = 0, world = 1;
     bool count_frags = true;   // exact covered-fragment statistic (disables whole-triangle early-z)
     int raster_nw = 0;         // option raster_nw: force 3 / 4 / 6 / 8 / 16 waves per tile workgroup (dev)
     int raster_occ = 0;        // option raster_occ: force the 6- or 8-waves-per-SIMD build of the tile kernel (dev)
@@ -124,15 +168,65 @@ int fail(frr_ctx *c, int code, const std::string &msg)
             return fail(c, FRR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
     } while (0)
 
+hipStream_t gstream_of(const frr_ctx *c) { return c->overlap ? c->gstream : c->stream; }
+
+// both streams idle
+int drain(frr_ctx *c)
+{
+    if (c->gstream) HIP_TRY(c, hipStreamSynchronize(c->gstream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FRR_OK;
+}
+
 template <typename T> int ensure(frr_ctx *c, T *&p, size_t &cap, size_t need)
 {
     if (need <= cap && p) return FRR_OK;
-    if (p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(p)); p = nullptr; cap = 0; }
+    if (p) { int rc = drain(c); if (rc != FRR_OK) return rc; HIP_TRY(c, hipFree(p)); p = nullptr; cap = 0; }
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, need * sizeof(T));
     if (e != hipSuccess) return fail(c, FRR_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
     p = (T *)q;
     cap = need;
+    return FRR_OK;
+}
+
+// ---- cross-stream ordering (no-ops when everything runs on one stream) ----------------------------------------------
+// the second stream waits until tile kernel `serial` (and every earlier one) is done
+int gstream_wait_tile(frr_ctx *c, uint64_t serial)
+{
+    if (!c->overlap || serial <= c->g_waited) return FRR_OK;
+    // (the ring holds the latest four; an older kernel is covered by waiting for the oldest one still in the ring)
+    const uint64_t s = std::max<uint64_t>(serial, c->tile_serial >= 3 ? c->tile_serial - 3 : 0);
+    HIP_TRY(c, hipStreamWaitEvent(c->gstream, c->ev_tile[s & 3], 0));
+    c->g_waited = s;
+    return FRR_OK;
+}
+// the second stream waits for everything the caller's stream holds so far (mesh data written by the caller)
+int gstream_join(frr_ctx *c)
+{
+    if (!c->overlap || !c->need_join) { c->need_join = false; return FRR_OK; }
+    HIP_TRY(c, hipEventRecord(c->ev_join, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->gstream, c->ev_join, 0));
+    c->need_join = false;
+    c->g_waited = c->tile_serial;
+    return FRR_OK;
+}
+// the caller's stream waits for what the second stream holds so far (binning -> tile kernel)
+int stream_wait_gstream(frr_ctx *c)
+{
+    if (!c->overlap) return FRR_OK;
+    hipEvent_t e = c->ev_bin[++c->bin_serial & 3];
+    HIP_TRY(c, hipEventRecord(e, c->gstream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, e, 0));
+    return FRR_OK;
+}
+// a tile kernel has just been launched: number it
+int tile_launched(frr_ctx *c, GeomSet &gs, BinSet *bs)
+{
+    ++c->tile_serial;
+    gs.last_reader = c->tile_serial;
+    if (bs) bs->last_reader = c->tile_serial;
+    if (c->overlap) HIP_TRY(c, hipEventRecord(c->ev_tile[c->tile_serial & 3], c->stream));
     return FRR_OK;
 }
 
@@ -144,12 +238,12 @@ hipEvent_t get_event(frr_ctx *c)
     return e;
 }
 struct ProfScope {
-    frr_ctx *c; int kid; hipEvent_t a = nullptr;
-    ProfScope(frr_ctx *c_, int kid_) : c(c_), kid(kid_)
+    frr_ctx *c; int kid; hipStream_t st; hipEvent_t a = nullptr;
+    ProfScope(frr_ctx *c_, int kid_, hipStream_t st_) : c(c_), kid(kid_), st(st_)
     {
         if ((c->prof_mask & (1u << kid)) && (c->prof_seen[kid]++ % c->prof_period) == 0) {
             a = get_event(c);
-            if (a && hipEventRecord(a, c->stream) != hipSuccess) { c->ev_pool.push_back(a); a = nullptr; }
+            if (a && hipEventRecord(a, st) != hipSuccess) { c->ev_pool.push_back(a); a = nullptr; }
         }
     }
     ~ProfScope()
@@ -157,7 +251,7 @@ struct ProfScope {
         // a sample whose events could not be created or recorded is dropped (frr_profile_get then reports fewer launches)
         if (!a) return;
         hipEvent_t b = get_event(c);
-        if (b && hipEventRecord(b, c->stream) == hipSuccess) { c->prof_pending.push_back({kid, a, b}); return; }
+        if (b && hipEventRecord(b, st) == hipSuccess) { c->prof_pending.push_back({kid, a, b}); return; }
         c->ev_pool.push_back(a);
         if (b) c->ev_pool.push_back(b);
     }
@@ -165,7 +259,7 @@ struct ProfScope {
 void prof_collect(frr_ctx *c)
 {
     if (c->prof_pending.empty()) return;
-    (void)hipStreamSynchronize(c->stream);
+    (void)drain(c);
     for (auto &r : c->prof_pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof_ms[r.kid] += ms; c->prof_n[r.kid]++; }
@@ -202,52 +296,44 @@ void refresh_dev_uniforms(frr_ctx *c)
     else { d.tex = nullptr; d.tex_w = d.tex_h = 0; }
 }
 
-constexpr uint32_t kClipGrid = 2048;      // workgroups of k_geom_clip (four wavefronts each, one triangle per wavefront and step)
-int check_frame_counters(frr_ctx *c, Counters *host)
+// Tile rows [t0, t1) of rank `rank` in the blocked layout: the first tiles_y % world ranks own one row more than the
+// others, so that no rank of world <= tiles_y is left without rows (34 rows over 8 ranks: 5,5,4,4,4,4,4,4)
+void blocked_rows(int tiles_y, int rank, int world, int *t0, int *t1)
 {
-    Counters h;
-    HIP_TRY(c, hipMemcpyAsync(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (host) *host = h;
-    c->clip_queue_auto = std::max(h.clip_block_max[0], h.clip_block_max[1]) > (uint32_t)CLIP_QUEUE_AT;
-    if (h.overflow) {
-        // grow what overflowed so that re-issuing the frame succeeds
-        if (h.overflow & 2u) {
-            const uint64_t worst = std::max<uint64_t>(h.bin_total, std::max<uint64_t>(h.seg_total[0], h.seg_total[1]));
-            size_t need = (size_t)(worst + worst / 4 + 1024);
-            if (ensure(c, c->bins, c->bin_cap, need) != FRR_OK) return FRR_ERR_NOMEM;
-            if (ensure(c, c->bins2, c->bin2_cap, need) != FRR_OK) return FRR_ERR_NOMEM;
-        }
-        if (h.overflow & 1u) c->fan_hint = (size_t)h.need_fans + h.need_fans / 8 + 1024;
-        return fail(c, FRR_ERR_CAPACITY, "device work list overflowed; capacity grown, re-issue the frame");
-    }
-    return FRR_OK;
+    const int q = tiles_y / world, r = tiles_y % world;
+    *t0 = rank * q + std::min(rank, r);
+    *t1 = *t0 + q + (rank < r ? 1 : 0);
 }
 
-template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks)
+constexpr uint32_t kClipGrid = 2048;      // workgroups of k_geom_clip (four wavefronts each, one triangle per wavefront and step)
+
+template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks, const DevUniforms &du)
 {
-    ProfScope p(c, KID_GEOM);
-    hipLaunchKernelGGL(k_geom_single<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni);
-    if (g.use_clipq) hipLaunchKernelGGL(k_geom_clip<VS>, dim3(std::min<uint32_t>(kClipGrid, nblocks * 4u)), dim3(GEOM_BLOCK), 0, c->stream, g, c->duni);
+    hipStream_t st = gstream_of(c);
+    ProfScope p(c, KID_GEOM, st);
+    hipLaunchKernelGGL(k_geom_single<VS>, dim3(nblocks), dim3(GEOM_BLOCK), 0, st, g, du);
+    if (g.use_clipq) hipLaunchKernelGGL(k_geom_clip<VS>, dim3(std::min<uint32_t>(kClipGrid, nblocks * 4u)), dim3(GEOM_BLOCK), 0, st, g, du);
 }
 
 // the geometry kernel for the VS of the mesh
-void launch_geometry_vs(frr_ctx *c, GeomArgs &g, uint32_t nblocks, int vs)
+void launch_geometry_vs(frr_ctx *c, GeomArgs &g, uint32_t nblocks, int vs, const DevUniforms &du)
 {
     switch (vs) {
-    case FRR_VS_CLIP: launch_geometry<FRR_VS_CLIP>(c, g, nblocks); break;
-    case FRR_VS_CLIP_COLOR: launch_geometry<FRR_VS_CLIP_COLOR>(c, g, nblocks); break;
-    case FRR_VS_PHONG: launch_geometry<FRR_VS_PHONG>(c, g, nblocks); break;
-    case FRR_VS_GOURAUD: launch_geometry<FRR_VS_GOURAUD>(c, g, nblocks); break;
+    case FRR_VS_CLIP: launch_geometry<FRR_VS_CLIP>(c, g, nblocks, du); break;
+    case FRR_VS_CLIP_COLOR: launch_geometry<FRR_VS_CLIP_COLOR>(c, g, nblocks, du); break;
+    case FRR_VS_PHONG: launch_geometry<FRR_VS_PHONG>(c, g, nblocks, du); break;
+    case FRR_VS_GOURAUD: launch_geometry<FRR_VS_GOURAUD>(c, g, nblocks, du); break;
     }
 }
-// the latest draw's block sums -> prefix (+ n_emit, the fan-capacity flag), if no binning launch has done it
+// the latest geometry pass's block sums -> prefix (+ n_emit, the fan-capacity flag), if no binning launch has done it
 int scan_now(frr_ctx *c)
 {
-    if (!c->scan_pending) return FRR_OK;
-    { ProfScope p(c, KID_GEOM_SCAN); hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, c->stream, c->block_sums, c->geom_nblocks, c->cnt, c->geom_slot, c->geom_fan_cap); }
+    FrameState &f = c->fs;
+    if (!f.scan_pending) return FRR_OK;
+    hipStream_t st = gstream_of(c);
+    { ProfScope p(c, KID_GEOM_SCAN, st); hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, st, c->gset[f.gpar].block_sums, c->gset[f.gpar].block_prefix, f.geom_nblocks, c->cnt, f.gpar, f.geom_fan_cap, f.geom_seq, c->epoch); }
     HIP_TRY(c, hipGetLastError());
-    c->scan_pending = false;
+    f.scan_pending = false;
     return FRR_OK;
 }
 
@@ -270,18 +356,18 @@ SpanShape span_shape(const frr_ctx *c, uint32_t grid, uint64_t ntris, int ps_id)
     return {4, 6};
 }
 
-template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uint32_t grid, const SpanShape sh)
+template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uint32_t grid, const SpanShape sh, const DevUniforms &du, bool count_frags)
 {
-    ProfScope p(c, KID_RASTER);
+    ProfScope p(c, KID_RASTER, c->stream);
     if (c->raster_sweep) {
-        hipLaunchKernelGGL((k_raster<K, PS>), dim3(grid), dim3(256), 0, c->stream, a, c->duni);
+        hipLaunchKernelGGL((k_raster<K, PS>), dim3(grid), dim3(256), 0, c->stream, a, du);
     } else {
         // the span algebra needs every coordinate it touches within +-SPAN_SAFE (no i32 wrap)
         const int win_safe = a.x0 >= -SPAN_SAFE && a.y0 >= -SPAN_SAFE && a.x1 <= SPAN_SAFE && a.y1 <= SPAN_SAFE;
         auto go = [&](auto count_tag, auto nw_tag, auto occ_tag) {
             constexpr bool CNT = decltype(count_tag)::value;
             constexpr int NWV = decltype(nw_tag)::value, OCCV = decltype(occ_tag)::value;
-            hipLaunchKernelGGL((k_raster_span<K, PS, CNT, NWV, OCCV>), dim3(grid), dim3(NWV * 64), 0, c->stream, a, c->duni, win_safe);
+            hipLaunchKernelGGL((k_raster_span<K, PS, CNT, NWV, OCCV>), dim3(grid), dim3(NWV * 64), 0, c->stream, a, du, win_safe);
         };
         auto go_nw = [&](auto count_tag) {
             if (sh.nw == LIGHT_NW) go(count_tag, std::integral_constant<int, LIGHT_NW>{}, std::integral_constant<int, 6>{});
@@ -291,8 +377,344 @@ template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uin
             else if (sh.nw == 8) go(count_tag, std::integral_constant<int, 8>{}, std::integral_constant<int, 6>{});
             else go(count_tag, std::integral_constant<int, 16>{}, std::integral_constant<int, 4>{});
         };
-        if (c->count_frags) go_nw(std::true_type{}); else go_nw(std::false_type{});
+        if (count_frags) go_nw(std::true_type{}); else go_nw(std::false_type{});
     }
+}
+
+// the clear itself (k_clear), on the caller's stream
+int clear_now(frr_ctx *c, uint32_t packed, float depth)
+{
+    const FrameState &f = c->fs;
+    const uint32_t n = c->W * c->H, n4 = n / 4;
+    {
+        ProfScope p(c, KID_CLEAR, c->stream);
+        uint32_t grid = std::min<uint32_t>((n4 + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_clear, dim3(grid ? grid : 1), dim3(256), 0, c->stream, (uint4 *)f.color, (uint4 *)f.depth,
+                           (uint4 *)f.tri_id, n4, packed, depth);
+        if (n4 * 4 < n)
+            hipLaunchKernelGGL(k_clear_tail, dim3(1), dim3(64), 0, c->stream, (uint32_t *)f.color, (uint32_t *)f.depth,
+                               f.tri_id, n4 * 4, n, packed, depth);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return FRR_OK;
+}
+
+// bring the targets to the state the API promises (a pending frr_clear; rows a fused clear of a partitioned ctx skipped)
+int settle_targets(frr_ctx *c)
+{
+    FrameState &f = c->fs;
+    if (f.clear_pending) {
+        int rc = clear_now(c, f.clear_rgba, f.clear_depth);
+        if (rc != FRR_OK) return rc;
+        f.clear_pending = f.unowned_debt = false;
+    } else if (f.unowned_debt) {
+        RowOwner own = {f.rank, f.world, f.part_blocked ? 1 : 0, 0, 0};
+        if (own.blocked) blocked_rows(f.debt_tiles_y, f.rank, f.world, &own.brow0, &own.brow1);
+        hipLaunchKernelGGL(k_clear_unowned_rows, dim3(c->H), dim3(256), 0, c->stream, (uint32_t *)f.color, (uint32_t *)f.depth,
+                           f.tri_id, c->W, c->H, own, f.clear_rgba, f.clear_depth);
+        HIP_TRY(c, hipGetLastError());
+        f.unowned_debt = false;
+    }
+    return FRR_OK;
+}
+// ... and the tables of the latest geometry pass (called by everything that looks at either)
+int settle(frr_ctx *c)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rcs = scan_now(c); if (rcs != FRR_OK) return rcs; }   // n_emit of the latest pass (statistics, setup read-back)
+    return settle_targets(c);
+}
+
+// ---- the two commands ------------------------------------------------------------------------------------------------
+// Loop A (phong.rs:321-331) over the mesh: one geometry pass.  Nothing of the host state is committed before the last
+// step that can fail.
+int exec_geometry(frr_ctx *c, Cmd &cmd)
+{
+    FrameState &f = c->fs;
+    const Mesh &m = c->meshes[cmd.mesh];
+    const int K = frr_vs_num_varyings(m.vs);
+    const uint64_t nt = m.ntris;
+    const int par = f.gpar ^ 1;
+    GeomSet &S = c->gset[par];
+    int rc;
+    // fan space: clipped inputs are the ones that straddle a frustum plane, usually few; room for as many fan triangles
+    // as there are inputs (+ 4096) to start with, grown on demand (the pass then fails on the device and finish() replays
+    // it with more) up to the worst case of 19 per input (small meshes get their worst case outright: 2^20 slots are cheap) ...
+    const uint32_t nblocks = (uint32_t)((nt + GEOM_BLOCK - 1) / GEOM_BLOCK);
+    // ... in FAN_REGIONS regions (block b allocates in region b % FAN_REGIONS: frr_device.h); a region never needs more
+    // than 19 slots for every input of the blocks that use it
+    const uint64_t region_worst = (uint64_t)FRR_MAX_OUT_TRIS * GEOM_BLOCK * ((nblocks + FAN_REGIONS - 1) / FAN_REGIONS);
+    uint64_t first_guess = std::max<uint64_t>((nt + 4096 + FAN_REGIONS - 1) / FAN_REGIONS, std::min<uint64_t>(region_worst, (1u << 20) / FAN_REGIONS));
+    if (c->fan_cap_init) first_guess = (c->fan_cap_init + FAN_REGIONS - 1) / FAN_REGIONS;   // option fan_capacity (tests of the replay)
+    uint64_t region = std::max<uint64_t>(first_guess, (c->fan_hint + FAN_REGIONS - 1) / FAN_REGIONS);
+    region = std::max<uint64_t>(std::min<uint64_t>(region, region_worst), 1);
+    uint64_t fan_cap = region * FAN_REGIONS;
+    if (nt + fan_cap > 0xFFFFFFF0ull) fan_cap = (0xFFFFFFF0ull - nt) / FAN_REGIONS * FAN_REGIONS;
+    const size_t slots = (size_t)(nt + fan_cap);
+    if ((rc = ensure(c, S.block_sums, S.block_sums_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
+    if ((rc = ensure(c, S.block_prefix, S.block_prefix_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
+    if ((rc = ensure(c, S.tinfo, S.tinfo_cap, (size_t)std::max<uint64_t>(nt, 1))) != FRR_OK) return rc;
+    if ((rc = ensure(c, S.fanbase, S.fanbase_cap, (size_t)std::max<uint64_t>(nt, 1))) != FRR_OK) return rc;
+    if ((rc = ensure(c, S.fan_okey, S.fan_okey_cap, (size_t)std::max<uint64_t>(fan_cap, 1))) != FRR_OK) return rc;
+    if ((rc = ensure(c, S.recs, S.setup_cap, std::max<size_t>(slots, 1024))) != FRR_OK) return rc;
+    if ((rc = ensure(c, S.pbox, S.pbox_cap, S.setup_cap)) != FRR_OK) return rc;
+    if ((rc = ensure(c, S.bcount, S.bcount_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
+    if (K > 0 && (rc = ensure(c, S.vary, S.vary_cap, (size_t)S.setup_cap * 3 * 8 /* K <= 8 in the shader table */)) != FRR_OK) return rc;
+    const bool use_clipq = nt > 0 && (c->clip_queue > 0 || (c->clip_queue < 0 && c->clip_queue_auto));
+    if (use_clipq && (rc = ensure(c, S.clipq, S.clipq_cap, (size_t)nt)) != FRR_OK) return rc;
+    if ((rc = scan_now(c)) != FRR_OK) return rc;   // the previous pass's n_emit feeds this pass's tri_base
+    // second stream: after whatever the caller's stream holds that this pass may read (first use), and after the tile
+    // kernel that last read this workspace
+    if ((rc = gstream_join(c)) != FRR_OK) return rc;
+    if ((rc = gstream_wait_tile(c, S.last_reader)) != FRR_OK) return rc;
+    GeomArgs g;
+    g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
+    g.fan_cap = (uint32_t)fan_cap;
+    g.seq = cmd.seq; g.epoch = c->epoch; g.frame_no = f.frame_no;
+    g.part_rank = f.rank; g.part_world = cmd.filter ? f.world : 1; g.part_y0 = cmd.fy0; g.part_y1 = cmd.fy1;
+    g.part_blocked = 0; g.part_brow0 = g.part_brow1 = 0;
+    if (cmd.filter && f.part_blocked) {
+        const int tiles_y = (int)(((int64_t)cmd.fy1 - cmd.fy0 + TILE - 1) / TILE);
+        g.part_blocked = 1;
+        blocked_rows(tiles_y, f.rank, f.world, &g.part_brow0, &g.part_brow1);
+    }
+    g.gpar = par;
+    g.block_sums = S.block_sums; g.block_prefix = S.block_prefix; g.tinfo = S.tinfo; g.fanbase = S.fanbase; g.fan_okey = S.fan_okey;
+    g.recs = S.recs; g.vary = S.vary; g.pbox = S.pbox; g.cnt = c->cnt;
+    g.clipq = S.clipq; g.use_clipq = use_clipq ? 1 : 0;
+    g.bcount = S.bcount;
+    // what the setup list about to be built was filtered by (frr_raster / frr_readback_setup check it)
+    f.geom_filter = GeomFilter{cmd.filter, cmd.fy0, cmd.fy1, f.rank, f.world, f.part_blocked};
+    f.gpar = par; cmd.par = par;
+    f.geom_fan_cap = (uint32_t)fan_cap;
+    f.geom_nblocks = nblocks;
+    f.geom_seq = cmd.seq;
+    f.geom_vs = m.vs; f.geom_ntris = nt;
+    f.tris_in += nt; f.draws += 1;
+    if (nt == 0) {
+        hipLaunchKernelGGL(k_geom_empty, dim3(1), dim3(64), 0, gstream_of(c), g);
+    } else {
+        launch_geometry_vs(c, g, nblocks, m.vs, cmd.duni);
+        f.scan_pending = true;
+    }
+    HIP_TRY(c, hipGetLastError());
+    return FRR_OK;
+}
+
+// Loop B (phong.rs:361-381): binning + tile kernel over the latest geometry pass, window (x0,x1) x (y0,y1)
+int exec_raster(frr_ctx *c, Cmd &cmd)
+{
+    FrameState &f = c->fs;
+    const int32_t x0 = cmd.x0, x1 = cmd.x1, y0 = cmd.y0, y1 = cmd.y1;
+    const int ps_id = cmd.ps;
+    const int64_t ww = (int64_t)x1 - x0, wh = (int64_t)y1 - y0;
+    bool fuse = false;
+    if (f.clear_pending) {
+        const bool full = x0 == 0 && y0 == 0 && x1 == (int32_t)c->W && y1 == (int32_t)c->H;
+        if (full && !c->raster_sweep) fuse = true; // the tile kernel performs the clear
+        else { int rcs = settle_targets(c); if (rcs != FRR_OK) return rcs; }
+    }
+    GeomSet &S = c->gset[f.gpar];
+    RasterArgs a;
+    a.fused_clear = fuse ? 1 : 0; a.clear_rgba = f.clear_rgba; a.clear_depth = f.clear_depth;
+    a.x0 = x0; a.x1 = x1; a.y0 = y0; a.y1 = y1; a.win_w = (int)ww; a.win_h = (int)wh;
+    a.cstride = (int)c->W; a.dstride = x1;
+    a.tiles_x = (int)((ww + TILE - 1) / TILE); a.tiles_y = (int)((wh + TILE - 1) / TILE);
+    a.tiles_x_magic = 0u; // set below once the grid is known (exact only for block indices and tile counts < 2^16)
+    a.rank = f.rank; a.world = f.world;
+    a.blocked = (f.part_blocked && f.world > 1) ? 1 : 0; a.brow0 = a.brow1 = 0;
+    if (a.blocked) blocked_rows(a.tiles_y, a.rank, a.world, &a.brow0, &a.brow1);
+    a.recs = S.recs; a.vary = S.vary; a.pbox = S.pbox; a.bcount = S.bcount;
+    a.tile_counts = c->tile_counts; a.tile_offsets = c->tile_offsets; a.tile_cursor = c->tile_cursor;
+    a.gpar = f.gpar; a.bpar = 0; a.seq = cmd.seq; a.epoch = c->epoch; a.frame_no = f.frame_no; a.geom_seq = f.geom_seq;
+    const uint32_t ntiles = (uint32_t)a.tiles_x * a.tiles_y;
+    a.color = f.color; a.depth = f.depth; a.tri_id = f.tri_id; a.cnt = c->cnt;
+#ifdef FRR_DEBUG_COUNTERS
+    if (!c->dbg_tiles && getenv("FRR_DEBUG_TILES")) {
+        if (hipMalloc((void **)&c->dbg_tiles, (size_t)c->max_tiles * 64) != hipSuccess) c->dbg_tiles = nullptr;
+    }
+    if (c->dbg_tiles) (void)hipMemsetAsync(c->dbg_tiles, 0, (size_t)c->max_tiles * 64, c->stream);
+    a.dbg_tiles = c->dbg_tiles;
+#endif
+    a.seg = nullptr; a.nseg = 0;
+    const int owned_rows = a.blocked ? a.brow1 - a.brow0 : (a.tiles_y > a.rank ? (a.tiles_y - a.rank + a.world - 1) / a.world : 0);
+    const uint32_t grid = (uint32_t)a.tiles_x * owned_rows;
+    if (a.tiles_x >= 2 && a.tiles_x < 65536 && grid < 65536u) a.tiles_x_magic = (uint32_t)(0x100000000ull / (uint64_t)a.tiles_x + 1ull);
+    const SpanShape sh = span_shape(c, grid, f.geom_ntris, ps_id);
+    const bool segmented = grid <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep;
+    const int q = segmented ? (f.bpar ^ 1) : 0;   // (the CSR fallback has one set of tile tables: it uses workspace 0 and overlaps nothing)
+    BinSet &B = c->bset[q];
+    int rc;
+    if (!B.bins) {
+        size_t want = std::max<size_t>((size_t)f.geom_ntris * 8 + 4 * (size_t)c->max_tiles, (size_t)1 << 22);
+        if (c->bin_cap_init) want = c->bin_cap_init;      // option bin_capacity (tests of the replay)
+        want = std::max(want, c->bset[q ^ 1].bin_cap);   // (what the other workspace has grown to)
+        if ((rc = ensure(c, B.bins, B.bin_cap, want)) != FRR_OK) return rc;
+        if ((rc = ensure(c, B.bins2, B.bin2_cap, want)) != FRR_OK) return rc;
+    }
+    a.bins2 = B.bins2;
+    a.bins = B.bins; a.bin_cap = (uint32_t)std::min<size_t>(B.bin_cap, 0xFFFFFFFFu);
+    hipStream_t gs = gstream_of(c);
+    if (segmented) {
+        const uint32_t ltiles = std::max<uint32_t>(grid, 1u);   // the binning numbers the rank's OWN tiles only (local_tile_row)
+        // segmented LDS multi-split (one launch, no per-entry global atomics): G chunk workgroups, ~3K triangles each
+        // (small meshes: one triangle per thread, so that the launch is not three workgroups doing all the work)
+        uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((f.geom_ntris + BIN_WG - 1) / BIN_WG, 1), BIN_MAX_G);
+        if (c->bin_g > 0) G = (uint32_t)std::min(c->bin_g, BIN_MAX_G);
+        G = std::min<uint32_t>(G, sh.nw == 3 ? 256u : (uint32_t)sh.nw * 64u); // the tile kernel reads one segment per thread (three waves: wave 0 reads a second one)
+        // (+ one workgroup that scans the geometry kernel's block sums, unless an earlier launch has; a binning workgroup
+        // fills a CU's LDS, so the launch stays within 256 workgroups: a 257th would wait for a whole one to finish)
+        int do_scan = f.scan_pending ? 1 : 0;
+        if (do_scan && G > 255u) G = 255u;
+        if ((rc = ensure(c, B.bin_matrix, B.bin_matrix_cap, (size_t)BIN_MAX_G * ((size_t)c->max_tiles + 1))) != FRR_OK) return rc;
+        // dynamic LDS: tile counters + as many staged 16-B records as fit (a chunk emits ~1.8 records per triangle)
+        constexpr size_t kLdsBudget = 160 * 1024 - 1024; // the kernel's static LDS is < 1 KB
+        const size_t hist_bytes = (((size_t)ltiles + 3) & ~(size_t)3) * sizeof(uint32_t);
+        const uint32_t stage_cap = (uint32_t)std::min<size_t>((kLdsBudget - hist_bytes) / 16, 9216);
+        const size_t lds = hist_bytes + (size_t)stage_cap * 16;
+        if (!c->lds_attr_set) {
+            HIP_TRY(c, hipFuncSetAttribute((const void *)k_bin_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+            c->lds_attr_set = true;
+        }
+        a.seg = B.bin_matrix; a.nseg = G; a.bpar = q;
+        // near-first copies (bins2): a fixed slot per tile, 8x the mean tile load, + an overflow arena of bin_cap records
+        uint64_t SL = std::max<uint64_t>(256, (f.geom_ntris * 16 + ntiles - 1) / ntiles);   // (per-tile load of the whole window: ownership does not change it)
+        SL = std::min<uint64_t>(SL, ((uint64_t)1 << 30) / ltiles);
+        if (c->ent_slot_override) SL = c->ent_slot_override;
+        a.ent_slot = (uint32_t)SL;
+        a.bin_cap = (uint32_t)std::min<size_t>(B.bin_cap, 0xBFFFFFFFu);
+        if ((rc = ensure(c, B.bins2, B.bin2_cap, (size_t)ltiles * SL + a.bin_cap)) != FRR_OK) return rc;
+        a.bins2 = B.bins2;
+        if ((rc = gstream_wait_tile(c, B.last_reader)) != FRR_OK) return rc;   // the tile kernel that last read this workspace
+        {
+            ProfScope p(c, KID_BIN_SEG, gs);
+            hipLaunchKernelGGL(k_bin_seg, dim3(G + do_scan), dim3(BIN_WG), lds, gs, a, ltiles, B.bin_matrix, stage_cap,
+                               f.geom_fan_cap, S.block_sums, S.block_prefix, f.geom_nblocks, do_scan);
+        }
+        f.scan_pending = false;
+        f.bpar = q;
+    } else {
+        // fallback for frames with more tiles than fit LDS counters: global atomics (one set of tile tables: after every
+        // tile kernel so far)
+        if ((rc = gstream_wait_tile(c, c->tile_serial)) != FRR_OK) return rc;
+        if ((rc = scan_now(c)) != FRR_OK) return rc;
+        const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((f.geom_ntris + f.geom_fan_cap + 255) / 256, 2048);
+        { ProfScope p(c, KID_BIN_COUNT, gs); hipLaunchKernelGGL(k_bin<false>, dim3(bin_grid), dim3(256), 0, gs, a, f.geom_fan_cap); }
+        { ProfScope p(c, KID_TILE_SCAN, gs); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, gs, a, ntiles); }
+        { ProfScope p(c, KID_BIN_FILL, gs); hipLaunchKernelGGL(k_bin<true>, dim3(bin_grid), dim3(256), 0, gs, a, f.geom_fan_cap); }
+    }
+    cmd.par = q;
+    HIP_TRY(c, hipGetLastError());
+    if ((rc = stream_wait_gstream(c)) != FRR_OK) return rc;   // the tile kernel runs on the caller's stream, after the binning
+    if (grid) {
+        switch (ps_id) {
+        case FRR_PS_DEPTH: launch_raster<0, FRR_PS_DEPTH>(c, a, grid, sh, cmd.duni, cmd.count_frags); break;
+        case FRR_PS_FLAT: launch_raster<0, FRR_PS_FLAT>(c, a, grid, sh, cmd.duni, cmd.count_frags); break;
+        case FRR_PS_COLOR: launch_raster<3, FRR_PS_COLOR>(c, a, grid, sh, cmd.duni, cmd.count_frags); break;
+        case FRR_PS_PHONG: launch_raster<8, FRR_PS_PHONG>(c, a, grid, sh, cmd.duni, cmd.count_frags); break;
+        case FRR_PS_BLINN: launch_raster<8, FRR_PS_BLINN>(c, a, grid, sh, cmd.duni, cmd.count_frags); break;
+        }
+    }
+    HIP_TRY(c, hipGetLastError());
+    if ((rc = tile_launched(c, S, &B)) != FRR_OK) return rc;
+    if (fuse) {
+        f.clear_pending = false;
+        // the tile rows of other ranks missed this clear: owed to the ctx's own targets (frr_readback shows the
+        // whole image); caller-bound targets of a partitioned ctx only ever have their owned rows defined
+        f.unowned_debt = f.world > 1 && f.color == c->own_color && f.depth == c->own_depth && f.tri_id == c->own_tri_id;
+        f.debt_tiles_y = a.tiles_y;
+    }
+    return FRR_OK;
+}
+
+int finish(frr_ctx *c);
+
+// run a command and remember it (finish() replays the commands from a failed one onwards)
+int exec_cmd(frr_ctx *c, Cmd cmd)
+{
+    cmd.pre = c->fs;
+    cmd.seq = c->next_seq++;
+    const int rc = cmd.kind == Cmd::GEOM ? exec_geometry(c, cmd) : exec_raster(c, cmd);
+    if (rc != FRR_OK) { c->fs = cmd.pre; return rc; }
+    c->log.push_back(cmd);
+    if (c->log.size() >= 4096 && !c->in_replay) return finish(c);   // (a caller that never synchronises: bound the log)
+    return FRR_OK;
+}
+
+// Synchronisation point: both streams drained, device counters on the host, and -- if a command found a work list too
+// small (Counters::first_bad) -- the list grown and the commands from that one onwards replayed, as often as it takes.
+// The reference's draw cannot fail (renderer.rs:269-384); neither can this one, short of running out of memory.
+int finish(frr_ctx *c)
+{
+    if (c->in_replay) return FRR_OK;
+    int rc = settle(c);
+    if (rc != FRR_OK) return rc;
+    for (int round = 0;; ++round) {
+        if ((rc = drain(c)) != FRR_OK) return rc;
+        HIP_TRY(c, hipMemcpy(&c->hc, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost));
+        Counters &h = c->hc;
+        c->clip_queue_auto = std::max(h.gtab[0].clip_block_max, h.gtab[1].clip_block_max) > (uint32_t)CLIP_QUEUE_AT;
+        const uint32_t bad = h.first_bad;
+        if (bad == SEQ_NONE || bad < c->epoch) break;
+        size_t i = 0;
+        while (i < c->log.size() && c->log[i].seq != bad) ++i;
+        if (i == c->log.size()) return fail(c, FRR_ERR_HIP, "internal error: the failed command is not in the log");
+        if (round == 8) return fail(c, FRR_ERR_CAPACITY, "device work lists still too small after eight replays");
+        // grow what was too small
+        if (h.overflow & 2u) {
+            const uint64_t worst = std::max<uint64_t>(h.bin_total, std::max<uint64_t>(h.btab[0].seg_total, h.btab[1].seg_total));
+            const size_t need = (size_t)(worst + worst / 4 + 1024);
+            for (BinSet &B : c->bset) {
+                if (!B.bins && &B != &c->bset[c->log[i].par]) continue;   // (a workspace nobody has used yet is sized when it is)
+                if ((rc = ensure(c, B.bins, B.bin_cap, std::max(need, B.bin_cap))) != FRR_OK) return rc;
+                if ((rc = ensure(c, B.bins2, B.bin2_cap, std::max(need, B.bin2_cap))) != FRR_OK) return rc;
+            }
+        }
+        if (h.overflow & 1u) {
+            const uint64_t nf = std::max(h.gtab[0].need_fans, h.gtab[1].need_fans);
+            c->fan_hint = std::max<size_t>(c->fan_hint, (size_t)(nf + nf / 8 + 1024));
+        }
+        // the device tables as they were before the failed command: it has used its own parity's cursors (and, when its
+        // block sums were scanned inside the next raster pass's binning launch, that pass has reserved bin space)
+        h.first_bad = SEQ_NONE; h.overflow = 0u;
+        for (size_t k = i; k < std::min(i + 2, c->log.size()); ++k) {
+            const Cmd &m = c->log[k];
+            if (m.kind == Cmd::GEOM && k == i) {
+                GeomTab &gt = h.gtab[m.par];
+                for (int r = 0; r < FAN_REGIONS; ++r) gt.fan_cursor[r].v = 0u;
+                gt.clip_q = 0u; gt.clip_block_max = 0u; gt.n_emit = 0u; gt.need_fans = 0u;
+            } else if (m.kind == Cmd::RASTER) {
+                h.btab[m.par].seg_total = 0ull; h.btab[m.par].ent_cursor = 0u;
+            }
+        }
+        HIP_TRY(c, hipMemcpy(c->cnt, &h, offsetof(Counters, dbg), hipMemcpyHostToDevice));
+        // replay
+        std::vector<Cmd> todo(c->log.begin() + (ptrdiff_t)i, c->log.end());
+        c->log.resize(i);
+        const FrameState now = c->fs;
+        c->fs = todo[0].pre;
+        c->epoch = c->next_seq;
+        c->in_replay = true;
+        ++c->replays;
+        for (const Cmd &m : todo) {
+            // what the caller set between the commands travels with them
+            c->fs.color = m.pre.color; c->fs.depth = m.pre.depth; c->fs.tri_id = m.pre.tri_id;
+            c->fs.rank = m.pre.rank; c->fs.world = m.pre.world; c->fs.part_blocked = m.pre.part_blocked;
+            if ((rc = exec_cmd(c, m)) != FRR_OK) { c->in_replay = false; return rc; }
+        }
+        c->in_replay = false;
+        c->fs.color = now.color; c->fs.depth = now.depth; c->fs.tri_id = now.tri_id;
+        c->fs.rank = now.rank; c->fs.world = now.world; c->fs.part_blocked = now.part_blocked;
+        if ((rc = settle(c)) != FRR_OK) return rc;
+    }
+    c->log.clear();
+    c->epoch = c->next_seq;
+    if (c->next_seq > 0xF0000000u) {   // sequence numbers start over (nothing is in flight)
+        const uint32_t none = SEQ_NONE;
+        HIP_TRY(c, hipMemcpy(&c->cnt->first_bad, &none, sizeof none, hipMemcpyHostToDevice));
+        c->next_seq = c->epoch = 1;
+    }
+    return FRR_OK;
 }
 
 } // namespace
@@ -339,6 +761,7 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     c->device = device; c->W = width; c->H = height;
     if (stream) c->stream = (hipStream_t)stream;
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FRR_ERR_HIP; } c->own_stream = true; }
+    if (hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking) != hipSuccess) { frr_destroy(c); return FRR_ERR_HIP; }
     const size_t npx = (size_t)width * height;
     bool ok = hipMalloc((void **)&c->own_color, npx * 4) == hipSuccess && hipMalloc((void **)&c->own_depth, npx * 4) == hipSuccess &&
               hipMalloc((void **)&c->own_tri_id, npx * 4) == hipSuccess && hipMalloc((void **)&c->cnt, sizeof(Counters)) == hipSuccess;
@@ -346,9 +769,17 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     ok = ok && hipMalloc((void **)&c->tile_counts, (c->max_tiles + 1) * 4) == hipSuccess &&
          hipMalloc((void **)&c->tile_offsets, (c->max_tiles + 1) * 4) == hipSuccess &&
          hipMalloc((void **)&c->tile_cursor, (c->max_tiles + 1) * 4) == hipSuccess;
+    for (auto &e : c->ev_tile) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    for (auto &e : c->ev_bin) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     if (!ok) { frr_destroy(c); return FRR_ERR_NOMEM; }
-    c->color = c->own_color; c->depth = c->own_depth; c->tri_id = c->own_tri_id;
-    (void)hipMemsetAsync(c->cnt, 0, sizeof(Counters), c->stream);
+    c->fs.color = c->own_color; c->fs.depth = c->own_depth; c->fs.tri_id = c->own_tri_id;
+    {
+        // tables of frame 0 (no frame has that number), no failed command
+        memset(&c->hc, 0, sizeof c->hc);
+        c->hc.first_bad = SEQ_NONE;
+        if (hipMemcpy(c->cnt, &c->hc, sizeof(Counters), hipMemcpyHostToDevice) != hipSuccess) { frr_destroy(c); return FRR_ERR_HIP; }
+    }
     (void)hipMemsetAsync(c->tile_counts, 0, (c->max_tiles + 1) * 4, c->stream);
     (void)hipMemsetAsync(c->own_color, 0, npx * 4, c->stream);      // FrameBuffer::new zero-fills (renderer.rs:423)
     (void)hipMemsetAsync(c->own_depth, 0, npx * 4, c->stream);
@@ -370,28 +801,33 @@ void frr_destroy(frr_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->gstream) (void)hipStreamSynchronize(c->gstream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
-    void *ptrs[] = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->block_sums, c->tinfo, c->fanbase, c->fan_okey, c->recs, c->vary, c->pbox, c->bcount, c->clipq,
-                    c->tile_counts, c->tile_offsets, c->tile_cursor, c->bins, c->bins2, c->bin_matrix};
+    std::vector<void *> ptrs = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->tile_counts, c->tile_offsets, c->tile_cursor};
+    for (GeomSet &S : c->gset) for (void *p : {(void *)S.block_sums, (void *)S.block_prefix, (void *)S.tinfo, (void *)S.fanbase, (void *)S.fan_okey, (void *)S.recs,
+                                               (void *)S.vary, (void *)S.pbox, (void *)S.bcount, (void *)S.clipq}) ptrs.push_back(p);
+    for (BinSet &B : c->bset) for (void *p : {(void *)B.bins, (void *)B.bins2, (void *)B.bin_matrix}) ptrs.push_back(p);
     for (void *p : ptrs) if (p) (void)hipFree(p);
 #ifdef FRR_DEBUG_COUNTERS
     if (c->dbg_tiles) (void)hipFree(c->dbg_tiles);
 #endif
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_tile) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_bin) if (e) (void)hipEventDestroy(e);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->gstream) (void)hipStreamDestroy(c->gstream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
-static int settle(frr_ctx *c); // deferred frr_clear, below
-
 int frr_set_option(frr_ctx *c, const char *name, int64_t v)
 {
     if (!c || !name) return FRR_ERR_INVALID;
-    { int rc = settle(c); if (rc != FRR_OK) return rc; }   // nothing half-done under the old setting
+    { int rc = finish(c); if (rc != FRR_OK) return rc; }   // nothing in flight, nothing to replay under the old setting
     const std::string n(name);
     if (n == "raster_sweep") c->raster_sweep = v != 0;
     else if (n == "raster_nw") { if (v != 0 && v != LIGHT_NW && v != 4 && v != 6 && v != 8 && v != 16) return fail(c, FRR_ERR_INVALID, "raster_nw: 0, 3, 4, 6, 8 or 16"); c->raster_nw = (int)v; }
@@ -402,6 +838,8 @@ int frr_set_option(frr_ctx *c, const char *name, int64_t v)
     else if (n == "tile_slot_records") { if (v < 0 || v > 0x7FFFFFFF) return fail(c, FRR_ERR_INVALID, "tile_slot_records out of range"); c->ent_slot_override = (uint32_t)v; }
     else if (n == "bin_atomics") c->bin_atomics = v != 0;
     else if (n == "bin_capacity") { if (v < 0) return fail(c, FRR_ERR_INVALID, "bin_capacity >= 0"); c->bin_cap_init = (size_t)v; }
+    else if (n == "fan_capacity") { if (v < 0) return fail(c, FRR_ERR_INVALID, "fan_capacity >= 0"); c->fan_cap_init = (size_t)v; }
+    else if (n == "overlap") { c->overlap = v != 0; c->need_join = true; }
     else return fail(c, FRR_ERR_INVALID, "unknown option");
     return FRR_OK;
 }
@@ -410,34 +848,35 @@ int frr_set_partition(frr_ctx *c, int rank, int world)
 {
     if (!c || world < 1 || rank < 0 || rank >= world) return fail(c, FRR_ERR_INVALID, "bad partition");
     { int rc = settle(c); if (rc != FRR_OK) return rc; } // rows skipped by a fused clear are defined by the old partition
-    c->rank = rank; c->world = world;
+    c->fs.rank = rank; c->fs.world = world;
     return FRR_OK;
 }
 int frr_set_partition_layout(frr_ctx *c, int blocked)
 {
     if (!c) return FRR_ERR_INVALID;
     { int rc = settle(c); if (rc != FRR_OK) return rc; }
-    c->part_blocked = blocked != 0;
+    c->fs.part_blocked = blocked != 0;
     return FRR_OK;
 }
 // owned tile rows of a window of `wh` pixel rows, by the same rule the kernels use (owns_tile_row)
 static int owned_band(const frr_ctx *c, int64_t wh, int band, int32_t *row0, int32_t *row1)
 {
+    const FrameState &f = c->fs;
     const int tiles_y = (int)((wh + TILE - 1) / TILE);
-    if (c->world <= 1) {
+    if (f.world <= 1) {
         if (row0) { *row0 = 0; *row1 = (int32_t)wh; }
         return wh > 0 ? 1 : 0;
     }
-    if (c->part_blocked) {
-        const int rpr = std::max(1, (tiles_y + c->world - 1) / c->world);
-        const int t0 = c->rank * rpr, t1 = std::min(tiles_y, (c->rank + 1) * rpr);
+    if (f.part_blocked) {
+        int t0, t1;
+        blocked_rows(tiles_y, f.rank, f.world, &t0, &t1);
         if (t1 <= t0) return 0;
         if (row0) { *row0 = t0 * TILE; *row1 = (int32_t)std::min<int64_t>(wh, (int64_t)t1 * TILE); }
         return 1;
     }
-    const int n = tiles_y > c->rank ? (tiles_y - c->rank + c->world - 1) / c->world : 0;
+    const int n = tiles_y > f.rank ? (tiles_y - f.rank + f.world - 1) / f.world : 0;
     if (row0 && band < n) {
-        const int ty = c->rank + band * c->world;
+        const int ty = f.rank + band * f.world;
         *row0 = ty * TILE; *row1 = (int32_t)std::min<int64_t>(wh, (int64_t)(ty + 1) * TILE);
     }
     return n;
@@ -467,18 +906,18 @@ int frr_bind_targets(frr_ctx *c, void *color, void *depth, void *tri_id)
 {
     if (!c) return FRR_ERR_INVALID;
     { int rc = settle(c); if (rc != FRR_OK) return rc; } // a pending clear belongs to the targets bound when it was issued
-    c->color = color ? (uint8_t *)color : c->own_color;
-    c->depth = depth ? (float *)depth : c->own_depth;
-    c->tri_id = tri_id ? (uint32_t *)tri_id : c->own_tri_id;
+    c->fs.color = color ? (uint8_t *)color : c->own_color;
+    c->fs.depth = depth ? (float *)depth : c->own_depth;
+    c->fs.tri_id = tri_id ? (uint32_t *)tri_id : c->own_tri_id;
     return FRR_OK;
 }
 int frr_target_ptrs(frr_ctx *c, void **color, void **depth, void **tri_id)
 {
     if (!c) return FRR_ERR_INVALID;
     { int rc = settle(c); if (rc != FRR_OK) return rc; } // the caller is about to look at them
-    if (color) *color = c->color;
-    if (depth) *depth = c->depth;
-    if (tri_id) *tri_id = c->tri_id;
+    if (color) *color = c->fs.color;
+    if (depth) *depth = c->fs.depth;
+    if (tri_id) *tri_id = c->fs.tri_id;
     return FRR_OK;
 }
 
@@ -511,12 +950,13 @@ int frr_mesh_bind_device(frr_ctx *c, const void *dev, uint64_t ntris, int vs_id,
     if (!c || !mesh_out || frr_vs_input_floats(vs_id) < 0 || (ntris && !dev)) return fail(c, FRR_ERR_INVALID, "bad mesh");
     if (ntris >= (1ull << 27)) return fail(c, FRR_ERR_UNSUPPORTED, "more than 2^27 triangles per mesh (order keys: 32 per input triangle)");
     if (((uintptr_t)dev & 15u) != 0) return fail(c, FRR_ERR_INVALID, "mesh pointer must be 16-byte aligned");
+    c->need_join = true;   // the geometry stream has to see what the caller's stream wrote into that memory up to now
     return mesh_register(c, (const float *)dev, false, ntris, vs_id, mesh_out);
 }
 int frr_mesh_free(frr_ctx *c, int mesh)
 {
     if (!c || mesh < 0 || mesh >= (int)c->meshes.size() || !c->meshes[mesh].used) return fail(c, FRR_ERR_INVALID, "bad mesh id");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc = finish(c); if (rc != FRR_OK) return rc; }   // nothing reads it any more, nothing will replay a draw of it
     if (c->meshes[mesh].owned) (void)hipFree((void *)c->meshes[mesh].dev);
     c->meshes[mesh] = Mesh();
     return FRR_OK;
@@ -527,7 +967,7 @@ int frr_texture_upload(frr_ctx *c, int slot, const uint8_t *rgba, uint32_t w, ui
     if (!c || slot < 0 || slot >= FRR_MAX_TEXTURES || !rgba || w == 0 || h == 0) return fail(c, FRR_ERR_INVALID, "bad texture");
     if (h < w) return fail(c, FRR_ERR_UNSUPPORTED, "texture height < width: sample_2d clamps y with width (renderer.rs:523) and would index out of bounds");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc = finish(c); if (rc != FRR_OK) return rc; }   // the draws issued so far sample the old texture
     Texture &t = c->tex[slot];
     if (t.dev) { (void)hipFree(t.dev); t.dev = nullptr; }
     size_t bytes = (size_t)w * h * 4;
@@ -547,141 +987,56 @@ int frr_set_uniforms(frr_ctx *c, const frr_uniforms *u)
     return FRR_OK;
 }
 
-// the clear itself (k_clear); `counters`: also reset the frame counters
-static int clear_now(frr_ctx *c, uint32_t packed, float depth, bool counters)
-{
-    const uint32_t n = c->W * c->H, n4 = n / 4;
-    {
-        ProfScope p(c, KID_CLEAR);
-        uint32_t grid = std::min<uint32_t>((n4 + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_clear, dim3(grid ? grid : 1), dim3(256), 0, c->stream, (uint4 *)c->color, (uint4 *)c->depth,
-                           (uint4 *)c->tri_id, n4, packed, depth, counters ? c->cnt : (Counters *)nullptr);
-        if (n4 * 4 < n)
-            hipLaunchKernelGGL(k_clear_tail, dim3(1), dim3(64), 0, c->stream, (uint32_t *)c->color, (uint32_t *)c->depth,
-                               c->tri_id, n4 * 4, n, packed, depth);
-    }
-    HIP_TRY(c, hipGetLastError());
-    return FRR_OK;
-}
-
-// bring targets and counters to the state the API promises (called by everything that looks at them)
-static int settle(frr_ctx *c)
-{
-    HIP_TRY(c, hipSetDevice(c->device));
-    { int rcs = scan_now(c); if (rcs != FRR_OK) return rcs; }   // n_emit of the latest draw (statistics, setup read-back)
-    if (c->clear_pending) {
-        int rc = clear_now(c, c->clear_rgba, c->clear_depth, c->counters_pending);
-        if (rc != FRR_OK) return rc;
-        c->clear_pending = c->counters_pending = c->unowned_debt = false;
-    } else if (c->unowned_debt) {
-        hipLaunchKernelGGL(k_clear_unowned_rows, dim3(c->H), dim3(256), 0, c->stream, (uint32_t *)c->color, (uint32_t *)c->depth,
-                           c->tri_id, c->W, c->H, c->rank, c->world, c->debt_rpr, c->clear_rgba, c->clear_depth);
-        HIP_TRY(c, hipGetLastError());
-        c->unowned_debt = false;
-    }
-    return FRR_OK;
-}
-
 int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
 {
     if (!c || !rgba) return FRR_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     uint32_t packed;
     memcpy(&packed, rgba, 4);
-    c->geom_ntris = 0;          // the setup list of a preceding frr_geometry is gone (frr_raster then draws nothing)
-    c->scan_pending = false;
-    if (c->clear_eager) return clear_now(c, packed, depth, true);
-    c->clear_rgba = packed; c->clear_depth = depth;
-    c->clear_pending = c->counters_pending = true;
-    c->unowned_debt = false; // superseded: the pending clear covers every row
+    FrameState &f = c->fs;
+    // A new frame: the commands logged so far are history.  (One of them may have failed unseen: it and everything after
+    // it left the targets untouched, and they are overwritten now.  Device statistics are tagged with the frame number.)
+    c->log.clear();
+    c->epoch = c->next_seq;
+    c->replays = 0;
+    f.frame_no += 1;
+    f.tris_in = 0; f.draws = 0;
+    f.geom_ntris = 0;          // the setup list of a preceding frr_geometry is gone (frr_raster then draws nothing)
+    f.scan_pending = false;
+    f.unowned_debt = false;    // superseded: the clear covers every row
+    if (c->clear_eager) { f.clear_pending = false; return clear_now(c, packed, depth); }
+    f.clear_rgba = packed; f.clear_depth = depth;
+    f.clear_pending = true;
     return FRR_OK;
 }
 
-static int geometry_impl(frr_ctx *c, int mesh, uint64_t *ntris_setup, bool filter, int32_t fy0, int32_t fy1)
+int frr_geometry(frr_ctx *c, int mesh, uint64_t *ntris_setup)
 {
     if (!c || mesh < 0 || mesh >= (int)c->meshes.size() || !c->meshes[mesh].used) return fail(c, FRR_ERR_INVALID, "bad mesh id");
     HIP_TRY(c, hipSetDevice(c->device));
-    const Mesh &m = c->meshes[mesh];
-    const int K = frr_vs_num_varyings(m.vs);
-    const uint64_t nt = m.ntris;
-    int rc;
-    if ((rc = scan_now(c)) != FRR_OK) return rc;   // the previous draw's n_emit feeds this draw's tri_base
-    // fan space: clipped inputs are the ones that straddle a frustum plane, usually few; room for as many fan triangles
-    // as there are inputs (+ 4096) to start with, grown on demand (FRR_ERR_CAPACITY: the frame is re-issued) up to the
-    // worst case of 19 per input (small meshes get their worst case outright: 2^20 slots are cheap) ...
-    const uint32_t nblocks = (uint32_t)((nt + GEOM_BLOCK - 1) / GEOM_BLOCK);
-    // ... in FAN_REGIONS regions (block b allocates in region b % FAN_REGIONS: frr_device.h); a region never needs more
-    // than 19 slots for every input of the blocks that use it
-    const uint64_t region_worst = (uint64_t)FRR_MAX_OUT_TRIS * GEOM_BLOCK * ((nblocks + FAN_REGIONS - 1) / FAN_REGIONS);
-    uint64_t region = std::max<uint64_t>(std::max<uint64_t>((nt + 4096 + FAN_REGIONS - 1) / FAN_REGIONS, std::min<uint64_t>(region_worst, (1u << 20) / FAN_REGIONS)),
-                                         (c->fan_hint + FAN_REGIONS - 1) / FAN_REGIONS);
-    region = std::max<uint64_t>(std::min<uint64_t>(region, region_worst), 1);
-    uint64_t fan_cap = region * FAN_REGIONS;
-    if (nt + fan_cap > 0xFFFFFFF0ull) fan_cap = (0xFFFFFFF0ull - nt) / FAN_REGIONS * FAN_REGIONS;
-    const size_t slots = (size_t)(nt + fan_cap);
-    if ((rc = ensure(c, c->block_sums, c->block_sums_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
-    if ((rc = ensure(c, c->tinfo, c->tinfo_cap, (size_t)std::max<uint64_t>(nt, 1))) != FRR_OK) return rc;
-    if ((rc = ensure(c, c->fanbase, c->fanbase_cap, (size_t)std::max<uint64_t>(nt, 1))) != FRR_OK) return rc;
-    if ((rc = ensure(c, c->fan_okey, c->fan_okey_cap, (size_t)std::max<uint64_t>(fan_cap, 1))) != FRR_OK) return rc;
-    if ((rc = ensure(c, c->recs, c->setup_cap, std::max<size_t>(slots, 1024))) != FRR_OK) return rc;
-    if ((rc = ensure(c, c->pbox, c->pbox_cap, c->setup_cap)) != FRR_OK) return rc;
-    if ((rc = ensure(c, c->bcount, c->bcount_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
-    if (K > 0 && (rc = ensure(c, c->vary, c->vary_cap, (size_t)c->setup_cap * 3 * 8 /* K <= 8 in the shader table */)) != FRR_OK) return rc;
-    const bool use_clipq = nt > 0 && (c->clip_queue > 0 || (c->clip_queue < 0 && c->clip_queue_auto));
-    if (use_clipq && (rc = ensure(c, c->clipq, c->clipq_cap, (size_t)nt)) != FRR_OK) return rc;
-    GeomArgs g;
-    g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
-    g.fan_cap = (uint32_t)fan_cap;
-    g.reset_frame = c->counters_pending ? 1 : 0; // (committed with the launch, below)
-    g.part_rank = c->rank; g.part_world = filter ? c->world : 1; g.part_y0 = fy0; g.part_y1 = fy1;
-    g.part_rpr = 0;
-    if (filter && c->part_blocked) {
-        const int tiles_y = (int)(((int64_t)fy1 - fy0 + TILE - 1) / TILE);
-        g.part_rpr = std::max(1, (tiles_y + c->world - 1) / c->world);
-    }
-    // the per-draw slot (fan cursor) alternates; everything is committed only now that nothing can fail any more
-    // (a failed allocation above must not leave a slot toggled that nobody zeroed)
-    const int slot = c->geom_slot ^ 1;
-    g.fslot = slot;
-    g.block_sums = c->block_sums; g.tinfo = c->tinfo; g.fanbase = c->fanbase; g.fan_okey = c->fan_okey;
-    g.recs = c->recs; g.vary = c->vary; g.pbox = c->pbox; g.cnt = c->cnt;
-    g.clipq = c->clipq; g.use_clipq = use_clipq ? 1 : 0;
-    g.bcount = c->bcount;
-    // what the setup list about to be built was filtered by (frr_raster / frr_readback_setup check it)
-    c->geom_filter = frr_ctx::GeomFilter{filter, fy0, fy1, c->rank, c->world, c->part_blocked};
-    c->geom_slot = slot;
-    c->geom_fan_cap = (uint32_t)fan_cap;
-    c->geom_nblocks = nblocks;
-    c->counters_pending = false;
-    c->geom_vs = m.vs; c->geom_ntris = nt;
-    if (nt == 0) {
-        hipLaunchKernelGGL(k_geom_empty, dim3(1), dim3(64), 0, c->stream, g);
-    } else {
-        launch_geometry_vs(c, g, nblocks, m.vs);
-        c->scan_pending = true;
-    }
-    HIP_TRY(c, hipGetLastError());
+    Cmd cmd;
+    cmd.kind = Cmd::GEOM; cmd.mesh = mesh; cmd.duni = c->duni;
+    int rc = exec_cmd(c, cmd);
+    if (rc != FRR_OK) return rc;
     if (ntris_setup) {
-        if ((rc = scan_now(c)) != FRR_OK) return rc;
-        Counters h;
-        if ((rc = check_frame_counters(c, &h)) < FRR_OK) return rc;
-        *ntris_setup = h.n_emit;
+        if ((rc = finish(c)) != FRR_OK) return rc;
+        *ntris_setup = c->hc.gtab[c->fs.gpar].n_emit;
     }
     return FRR_OK;
 }
 
-int frr_geometry(frr_ctx *c, int mesh, uint64_t *ntris_setup) { return geometry_impl(c, mesh, ntris_setup, false, 0, 0); }
-
-int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1)
+// argument checks of frr_raster; *nothing: the call is valid and draws nothing
+static int raster_check(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1, bool *nothing)
 {
-    if (!c || c->geom_vs < 0) return fail(c, FRR_ERR_INVALID, "frr_raster before frr_geometry");
+    const FrameState &f = c->fs;
+    if (f.geom_vs < 0) return fail(c, FRR_ERR_INVALID, "frr_raster before frr_geometry");
     if (x0 > x1 || y0 > y1) return fail(c, FRR_ERR_INVALID, "range min > max (i32::clamp would panic, renderer.rs:285)");
     const int64_t ww = (int64_t)x1 - x0, wh = (int64_t)y1 - y0;
     if (ww > (int64_t)c->W || wh > (int64_t)c->H) return fail(c, FRR_ERR_INVALID, "window larger than the FrameBuffer");
     if (x0 < -32768 || y0 < -32768 || x1 > 32767 || y1 > 32767) return fail(c, FRR_ERR_UNSUPPORTED, "window coordinates outside the i16 range");
     if (ww > 0 && wh > 0 && (x1 <= 0 || (wh - 1) * (int64_t)x1 + ww > (int64_t)c->W * c->H))
         return fail(c, FRR_ERR_INVALID, "depth index (cy-y0)*x1+(cx-x0) would leave the depth buffer (renderer.rs:362)");
-    const int K = frr_vs_num_varyings(c->geom_vs);
+    const int K = frr_vs_num_varyings(f.geom_vs);
     if ((ps_id == FRR_PS_COLOR && K != 3) || ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && K != 8) || ps_id < 0 || ps_id > FRR_PS_BLINN)
         return fail(c, FRR_ERR_INVALID, "pixel shader does not match the vertex shader's varyings");
     if ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && !c->duni.tex) return fail(c, FRR_ERR_INVALID, "no texture bound to uniforms.texture_slot");
@@ -689,123 +1044,37 @@ int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_
         // frr_draw on a partitioned ctx keeps only the triangles that touch the rank's tile rows of ITS window; that
         // list serves no other window or partition (the reference may reuse one geometry for several ranges,
         // renderer.rs:269-271: use frr_geometry for that, it never filters)
-        const frr_ctx::GeomFilter &gf = c->geom_filter;
-        if (gf.active && (gf.y0 != y0 || gf.y1 != y1 || gf.rank != c->rank || gf.world != c->world || gf.blocked != c->part_blocked))
+        const GeomFilter &gf = f.geom_filter;
+        if (gf.active && (gf.y0 != y0 || gf.y1 != y1 || gf.rank != f.rank || gf.world != f.world || gf.blocked != f.part_blocked))
             return fail(c, FRR_ERR_INVALID, "the setup list was filtered by frr_draw for another window/partition; re-run frr_geometry (unfiltered) before frr_raster");
     }
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (ww == 0 || wh == 0 || c->geom_ntris == 0) return FRR_OK;
-    bool fuse = false;
-    if (c->clear_pending) {
-        const bool full = x0 == 0 && y0 == 0 && x1 == (int32_t)c->W && y1 == (int32_t)c->H;
-        if (full && !c->counters_pending && !c->raster_sweep) fuse = true; // the tile kernel performs the clear
-        else { int rcs = settle(c); if (rcs != FRR_OK) return rcs; }
-    }
-    RasterArgs a;
-    a.fused_clear = fuse ? 1 : 0; a.clear_rgba = c->clear_rgba; a.clear_depth = c->clear_depth;
-    a.x0 = x0; a.x1 = x1; a.y0 = y0; a.y1 = y1; a.win_w = (int)ww; a.win_h = (int)wh;
-    a.cstride = (int)c->W; a.dstride = x1;
-    a.tiles_x = (int)((ww + TILE - 1) / TILE); a.tiles_y = (int)((wh + TILE - 1) / TILE);
-    a.tiles_x_magic = 0u; // set below once the grid is known (exact only for block indices and tile counts < 2^16)
-    a.rank = c->rank; a.world = c->world;
-    a.rpr = (c->part_blocked && c->world > 1) ? std::max(1, (a.tiles_y + c->world - 1) / c->world) : 0;
-    a.recs = c->recs; a.vary = c->vary; a.pbox = c->pbox; a.bcount = c->bcount;
-    a.tile_counts = c->tile_counts; a.tile_offsets = c->tile_offsets; a.tile_cursor = c->tile_cursor;
-    const uint32_t ntiles = (uint32_t)a.tiles_x * a.tiles_y;
-    int rc;
-    if (!c->bins) {
-        size_t want = std::max<size_t>((size_t)c->geom_ntris * 8 + 4 * (size_t)c->max_tiles, (size_t)1 << 22);
-        if (c->bin_cap_init) want = c->bin_cap_init;
-        if ((rc = ensure(c, c->bins, c->bin_cap, want)) != FRR_OK) return rc;
-        if ((rc = ensure(c, c->bins2, c->bin2_cap, want)) != FRR_OK) return rc;
-    }
-    a.bins2 = c->bins2;
-    a.bins = c->bins; a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xFFFFFFFFu);
-    a.color = c->color; a.depth = c->depth; a.tri_id = c->tri_id; a.cnt = c->cnt;
-#ifdef FRR_DEBUG_COUNTERS
-    if (!c->dbg_tiles && getenv("FRR_DEBUG_TILES")) {
-        if (hipMalloc((void **)&c->dbg_tiles, (size_t)c->max_tiles * 64) != hipSuccess) c->dbg_tiles = nullptr;
-    }
-    if (c->dbg_tiles) (void)hipMemsetAsync(c->dbg_tiles, 0, (size_t)c->max_tiles * 64, c->stream);
-    a.dbg_tiles = c->dbg_tiles;
-#endif
-    a.seg = nullptr; a.nseg = 0; a.slot = 0;
-    const int owned_rows = a.rpr > 0 ? std::max(0, std::min(a.tiles_y, (a.rank + 1) * a.rpr) - a.rank * a.rpr)
-                                     : (a.tiles_y > a.rank ? (a.tiles_y - a.rank + a.world - 1) / a.world : 0);
-    const uint32_t grid = (uint32_t)a.tiles_x * owned_rows;
-    if (a.tiles_x >= 2 && a.tiles_x < 65536 && grid < 65536u) a.tiles_x_magic = (uint32_t)(0x100000000ull / (uint64_t)a.tiles_x + 1ull);
-    const SpanShape sh = span_shape(c, grid, c->geom_ntris, ps_id);
-    if (grid <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep) {
-        const uint32_t ltiles = std::max<uint32_t>(grid, 1u);   // the binning numbers the rank's OWN tiles only (local_tile_row)
-        // segmented LDS multi-split (one launch, no per-entry global atomics): G chunk workgroups, ~3K triangles each
-        // (small meshes: one triangle per thread, so that the launch is not three workgroups doing all the work)
-        uint32_t G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((c->geom_ntris + BIN_WG - 1) / BIN_WG, 1), BIN_MAX_G);
-        if (c->bin_g > 0) G = (uint32_t)std::min(c->bin_g, BIN_MAX_G);
-        G = std::min<uint32_t>(G, sh.nw == 3 ? 256u : (uint32_t)sh.nw * 64u); // the tile kernel reads one segment per thread (three waves: wave 0 reads a second one)
-        // (+ one workgroup that scans the geometry kernel's block sums, unless an earlier launch has; a binning workgroup
-        // fills a CU's LDS, so the launch stays within 256 workgroups: a 257th would wait for a whole one to finish)
-        int do_scan = c->scan_pending ? 1 : 0;
-        if (do_scan && G > 255u) G = 255u;
-        if ((rc = ensure(c, c->bin_matrix, c->bin_matrix_cap, (size_t)BIN_MAX_G * ((size_t)c->max_tiles + 1))) != FRR_OK) return rc;
-        // dynamic LDS: tile counters + as many staged 16-B records as fit (a chunk emits ~1.8 records per triangle)
-        constexpr size_t kLdsBudget = 160 * 1024 - 1024; // the kernel's static LDS is < 1 KB
-        const size_t hist_bytes = (((size_t)ltiles + 3) & ~(size_t)3) * sizeof(uint32_t);
-        const uint32_t stage_cap = (uint32_t)std::min<size_t>((kLdsBudget - hist_bytes) / 16, 9216);
-        const size_t lds = hist_bytes + (size_t)stage_cap * 16;
-        if (!c->lds_attr_set) {
-            HIP_TRY(c, hipFuncSetAttribute((const void *)k_bin_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-            c->lds_attr_set = true;
-        }
-        c->bin_slot ^= 1;
-        a.seg = c->bin_matrix; a.nseg = G; a.slot = c->bin_slot;
-        // near-first copies (bins2): a fixed slot per tile, 8x the mean tile load, + an overflow arena of bin_cap records
-        uint64_t S = std::max<uint64_t>(256, (c->geom_ntris * 16 + ntiles - 1) / ntiles);   // (per-tile load of the whole window: ownership does not change it)
-        S = std::min<uint64_t>(S, ((uint64_t)1 << 30) / ltiles);
-        if (c->ent_slot_override) S = c->ent_slot_override;
-        a.ent_slot = (uint32_t)S;
-        a.bin_cap = (uint32_t)std::min<size_t>(c->bin_cap, 0xBFFFFFFFu);
-        if ((rc = ensure(c, c->bins2, c->bin2_cap, (size_t)ltiles * S + a.bin_cap)) != FRR_OK) return rc;
-        a.bins2 = c->bins2;
-        {
-            ProfScope p(c, KID_BIN_SEG);
-            hipLaunchKernelGGL(k_bin_seg, dim3(G + do_scan), dim3(BIN_WG), lds, c->stream, a, ltiles, c->bin_matrix, a.slot, stage_cap,
-                               c->geom_slot, c->geom_fan_cap, c->block_sums, c->geom_nblocks, do_scan);
-        }
-        c->scan_pending = false;
-    } else {
-        // fallback for frames with more tiles than fit LDS counters: global atomics
-        if ((rc = scan_now(c)) != FRR_OK) return rc;
-        const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((c->geom_ntris + c->geom_fan_cap + 255) / 256, 2048);
-        { ProfScope p(c, KID_BIN_COUNT); hipLaunchKernelGGL(k_bin<false>, dim3(bin_grid), dim3(256), 0, c->stream, a, c->geom_slot, c->geom_fan_cap); }
-        { ProfScope p(c, KID_TILE_SCAN); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, a, ntiles); }
-        { ProfScope p(c, KID_BIN_FILL); hipLaunchKernelGGL(k_bin<true>, dim3(bin_grid), dim3(256), 0, c->stream, a, c->geom_slot, c->geom_fan_cap); }
-    }
-    if (grid) {
-        switch (ps_id) {
-        case FRR_PS_DEPTH: launch_raster<0, FRR_PS_DEPTH>(c, a, grid, sh); break;
-        case FRR_PS_FLAT: launch_raster<0, FRR_PS_FLAT>(c, a, grid, sh); break;
-        case FRR_PS_COLOR: launch_raster<3, FRR_PS_COLOR>(c, a, grid, sh); break;
-        case FRR_PS_PHONG: launch_raster<8, FRR_PS_PHONG>(c, a, grid, sh); break;
-        case FRR_PS_BLINN: launch_raster<8, FRR_PS_BLINN>(c, a, grid, sh); break;
-        }
-    }
-    HIP_TRY(c, hipGetLastError());
-    if (fuse) {
-        c->clear_pending = false;
-        // the tile rows of other ranks missed this clear: owed to the ctx's own targets (frr_readback shows the
-        // whole image); caller-bound targets of a partitioned ctx only ever have their owned rows defined
-        c->unowned_debt = c->world > 1 && c->color == c->own_color && c->depth == c->own_depth && c->tri_id == c->own_tri_id;
-        c->debt_rpr = a.rpr;
-    }
+    *nothing = ww == 0 || wh == 0 || f.geom_ntris == 0;
     return FRR_OK;
+}
+
+int frr_raster(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1)
+{
+    if (!c) return FRR_ERR_INVALID;
+    bool nothing = false;
+    const int rc = raster_check(c, ps_id, x0, x1, y0, y1, &nothing);
+    if (rc != FRR_OK || nothing) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    Cmd cmd;
+    cmd.kind = Cmd::RASTER; cmd.ps = ps_id; cmd.x0 = x0; cmd.x1 = x1; cmd.y0 = y0; cmd.y1 = y1;
+    cmd.count_frags = c->count_frags; cmd.duni = c->duni;
+    return exec_cmd(c, cmd);
 }
 
 int frr_draw(frr_ctx *c, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1)
 {
+    if (!c || mesh < 0 || mesh >= (int)c->meshes.size() || !c->meshes[mesh].used) return fail(c, FRR_ERR_INVALID, "bad mesh id");
+    HIP_TRY(c, hipSetDevice(c->device));
     // frr_draw knows the raster window, so a partitioned ctx can skip the setup records of triangles
     // that touch none of its tile rows (frr_geometry alone cannot: the window comes later)
-    const bool filter = c && c->world > 1 && y0 <= y1;
-    int rc = geometry_impl(c, mesh, nullptr, filter, y0, y1);
+    Cmd cmd;
+    cmd.kind = Cmd::GEOM; cmd.mesh = mesh; cmd.duni = c->duni;
+    cmd.filter = c->fs.world > 1 && y0 <= y1; cmd.fy0 = y0; cmd.fy1 = y1;
+    const int rc = exec_cmd(c, cmd);
     if (rc != FRR_OK) return rc;
     return frr_raster(c, ps_id, x0, x1, y0, y1);
 }
@@ -813,50 +1082,50 @@ int frr_draw(frr_ctx *c, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0
 int frr_sync(frr_ctx *c)
 {
     if (!c) return FRR_ERR_INVALID;
-    { int rc = settle(c); if (rc != FRR_OK) return rc; }
-    return check_frame_counters(c, nullptr);
+    return finish(c);
 }
 
 int frr_readback(frr_ctx *c, uint8_t *rgba, float *depth, uint32_t *tri_id)
 {
     if (!c) return FRR_ERR_INVALID;
-    { int rc = settle(c); if (rc != FRR_OK) return rc; }
+    { int rc = finish(c); if (rc != FRR_OK) return rc; }
     const size_t bytes = (size_t)c->W * c->H * 4;
-    if (rgba) HIP_TRY(c, hipMemcpyAsync(rgba, c->color, bytes, hipMemcpyDeviceToHost, c->stream));
-    if (depth) HIP_TRY(c, hipMemcpyAsync(depth, c->depth, bytes, hipMemcpyDeviceToHost, c->stream));
-    if (tri_id) HIP_TRY(c, hipMemcpyAsync(tri_id, c->tri_id, bytes, hipMemcpyDeviceToHost, c->stream));
-    return check_frame_counters(c, nullptr);
+    if (rgba) HIP_TRY(c, hipMemcpyAsync(rgba, c->fs.color, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (depth) HIP_TRY(c, hipMemcpyAsync(depth, c->fs.depth, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (tri_id) HIP_TRY(c, hipMemcpyAsync(tri_id, c->fs.tri_id, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FRR_OK;
 }
 
 int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uint64_t *ntris)
 {
-    if (!c || !ntris || c->geom_vs < 0) return fail(c, FRR_ERR_INVALID, "no geometry to read back");
-    if (c->geom_filter.active)
+    if (!c || !ntris || c->fs.geom_vs < 0) return fail(c, FRR_ERR_INVALID, "no geometry to read back");
+    if (c->fs.geom_filter.active)
         return fail(c, FRR_ERR_INVALID, "the setup list of a partitioned frr_draw holds only this rank's triangles; use frr_geometry to read back the full Vec<[Vertex;3]>");
-    { int rcs = settle(c); if (rcs != FRR_OK) return rcs; }
-    Counters h;
-    const int rc_frame = check_frame_counters(c, &h);
-    if (rc_frame < FRR_OK) return rc_frame;
-    *ntris = h.n_emit;
-    if (!out) return rc_frame;
+    { int rcs = finish(c); if (rcs != FRR_OK) return rcs; }
+    const FrameState &f = c->fs;
+    const GeomTab &gt = c->hc.gtab[f.gpar];
+    const GeomSet &S = c->gset[f.gpar];
+    const uint64_t nt = f.geom_ntris;
+    *ntris = nt ? gt.n_emit : 0;
+    if (!out || !nt) return FRR_OK;
     // the records live at slots (frr_device.h): input t's own slot, or its fan's slots behind the inputs; walking the
     // inputs in order and each fan in order is the reference's emission order
-    const uint64_t nt = c->geom_ntris;
-    const uint64_t slots = nt + c->geom_fan_cap;   // (fan slots are spread over the regions of the fan space)
-    const int K = frr_vs_num_varyings(c->geom_vs);
+    const uint64_t slots = nt + f.geom_fan_cap;   // (fan slots are spread over the regions of the fan space)
+    const int K = frr_vs_num_varyings(f.geom_vs);
     std::vector<uint32_t> tinfo(nt), fanbase(nt);
     std::vector<RasterRec> recs(slots);
     std::vector<float> vary((size_t)slots * 3 * K);
-    if (nt) HIP_TRY(c, hipMemcpy(tinfo.data(), c->tinfo, nt * 4, hipMemcpyDeviceToHost));
-    if (nt) HIP_TRY(c, hipMemcpy(fanbase.data(), c->fanbase, nt * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(tinfo.data(), S.tinfo, nt * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(fanbase.data(), S.fanbase, nt * 4, hipMemcpyDeviceToHost));
     // the inputs' own slots, then the used part of every fan region
-    const uint64_t region = c->geom_fan_cap / FAN_REGIONS;
+    const uint64_t region = f.geom_fan_cap / FAN_REGIONS;
     for (int k = -1; k < FAN_REGIONS; ++k) {
         const uint64_t first = k < 0 ? 0 : nt + (uint64_t)k * region;
-        const uint64_t count = k < 0 ? nt : std::min<uint64_t>(h.fan_cursor[c->geom_slot][k].v, region);
+        const uint64_t count = k < 0 ? nt : std::min<uint64_t>(gt.fan_cursor[k].v, region);
         if (!count) continue;
-        HIP_TRY(c, hipMemcpy(recs.data() + first, c->recs + first, count * sizeof(RasterRec), hipMemcpyDeviceToHost));
-        if (K) HIP_TRY(c, hipMemcpy(vary.data() + first * 3 * K, c->vary + first * 3 * K, count * 3 * K * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(recs.data() + first, S.recs + first, count * sizeof(RasterRec), hipMemcpyDeviceToHost));
+        if (K) HIP_TRY(c, hipMemcpy(vary.data() + first * 3 * K, S.vary + first * 3 * K, count * 3 * K * sizeof(float), hipMemcpyDeviceToHost));
     }
     uint64_t i = 0;
     for (uint64_t t = 0; t < nt && i < cap_tris; ++t) {
@@ -877,24 +1146,28 @@ int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uin
             }
         }
     }
-    return rc_frame;
+    return FRR_OK;
 }
 
 int frr_get_stats(frr_ctx *c, frr_stats *out)
 {
     if (!c || !out) return FRR_ERR_INVALID;
-    { int rc = settle(c); if (rc != FRR_OK) return rc; }
-    Counters h;
-    HIP_TRY(c, hipMemcpyAsync(&h, c->cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->clip_queue_auto = std::max(h.clip_block_max[0], h.clip_block_max[1]) > (uint32_t)CLIP_QUEUE_AT;
-    out->tris_in = h.tris_in;
-    out->tris_setup = (uint64_t)h.tri_base + h.n_emit;   // (settle() has scanned the latest draw's block sums)
-    out->bin_entries = h.bin_entries_frame + h.seg_total[0] + h.seg_total[1];
-    out->frag_covered = h.frag_covered;
-    out->frag_nan = h.frag_nan;
-    out->draws = h.draws;
-    out->overflow = h.overflow;
+    { int rc = finish(c); if (rc != FRR_OK) return rc; }
+    const FrameState &f = c->fs;
+    const Counters &h = c->hc;
+    const bool tot = h.totals_frame == f.frame_no;
+    memset(out, 0, sizeof *out);
+    out->tris_in = f.tris_in;
+    out->draws = f.draws;
+    out->replays = c->replays;
+    out->frag_covered = tot ? h.tot_frag_covered : 0;
+    out->frag_nan = tot ? h.tot_frag_nan : 0;
+    out->bin_entries = tot ? h.tot_bin_entries : 0;
+    for (int p = 0; p < 2; ++p) {
+        if (h.gtab[p].frame_no == f.frame_no) { out->frag_covered += h.gtab[p].frag_covered; out->frag_nan += h.gtab[p].frag_nan; }
+        if (h.btab[p].frame_no == f.frame_no) out->bin_entries += h.btab[p].seg_total;
+    }
+    if (f.draws && h.gtab[f.gpar].frame_no == f.frame_no) out->tris_setup = (uint64_t)h.gtab[f.gpar].tri_base + h.gtab[f.gpar].n_emit;
 #ifdef FRR_DEBUG_COUNTERS
     if (getenv("FRR_DEBUG_PRINT")) {
         fprintf(stderr, "frr dbg:");

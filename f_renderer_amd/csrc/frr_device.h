@@ -39,35 +39,72 @@ constexpr int DBG_COPIES = 1;
 constexpr int FAN_REGIONS = 8;
 struct alignas(128) FanCursor { uint32_t v; uint32_t pad[31]; };
 
-struct Counters {
-    uint32_t n_emit;        // triangles the current draw emits (the reference's count; known once the block sums are scanned)
-    uint32_t tri_base;      // emission index of this draw's first triangle within the frame
-    uint32_t overflow;      // bit0 fan capacity, bit1 bin capacity, bit2 order keys exhausted
-    uint32_t ntris_draw;    // input triangles of the current draw (= its first fan slot)
-    uint64_t bin_total;     // (triangle,tile) pairs of the current draw (CSR binning)
-    uint64_t frag_covered;  // since last clear
-    uint64_t frag_nan;
-    uint64_t tris_in;
-    uint64_t bin_entries_frame;
-    uint32_t draws;
-    uint32_t need_fans;     // fan slots the current draw needs (valid even on overflow)
-    uint32_t reserved0;
-    uint32_t skip_prev_bins; // set by the frame reset: the other binning slot holds the PREVIOUS frame's count, not to be added
-    unsigned long long seg_total[2]; // segmented binning: entries reserved by the current / previous draw (slots alternate per draw)
-    FanCursor fan_cursor[2][FAN_REGIONS]; // fan slots handed out per region by the current / previous draw's geometry kernel (slots alternate)
-    uint32_t ent_cursor[2];          // tile kernel: space handed out in the overflow arena of bins2 (same slots)
-    uint32_t clip_q[2];              // geometry: clipped inputs handed to the clip kernel's queue (GeomArgs::clipq; same slots as fan_cursor)
-    uint32_t clip_block_max[2];      // geometry: the most clipped inputs any one 256-triangle block had (the host's hint for that queue)
-    // per-draw tables the tile kernel's resolve reads (set by the geometry kernel; kernel arguments would cost it registers)
+// Per-geometry-pass table, double-buffered by the parity of the pass: the tile kernel of pass n reads table n & 1 while the
+// geometry kernel of pass n + 1 (on the ctx's second stream) already fills the other one.
+struct GeomTab {
+    uint32_t n_emit;        // triangles this pass emits (the reference's count; known once the block sums are scanned)
+    uint32_t tri_base;      // emission index of this pass's first triangle within the frame
+    uint32_t ntris_draw;    // input triangles of this pass (= its first fan slot)
+    uint32_t need_fans;     // fan slots this pass needs (valid even on overflow)
+    uint32_t frame_no;      // the frame (frr_clear count) this pass belongs to: statistics of older frames are not folded
+    uint32_t clip_q;        // clipped inputs handed to the clip kernel's queue (GeomArgs::clipq)
+    uint32_t clip_block_max; // the most clipped inputs any one 256-triangle block had (the host's hint for that queue)
+    uint32_t pad0;
+    // per-pass tables the tile kernel's resolve reads (set by the geometry kernel; kernel arguments would cost it registers)
     const uint32_t *tinfo;           // [ntris] fan size (bits 0-4) | emission offset within its 256-triangle block (bits 5..)
     const uint32_t *fanbase;         // [ntris] clipped inputs: first fan slot, relative to ntris_draw
     const uint32_t *fan_okey;        // [fan slots] order key (within the draw) of each fan triangle
     const uint32_t *block_prefix;    // [blocks] triangles emitted by the blocks before (exclusive scan of the block sums)
+    unsigned long long frag_covered; // by the tile kernels that rasterize this pass
+    unsigned long long frag_nan;
+    FanCursor fan_cursor[FAN_REGIONS]; // fan slots handed out per region (zeroed by the pass BEFORE: it runs beside nobody who uses them)
+};
+// Per-binning table (segmented binning), same double buffering by the parity of the raster pass.
+struct BinTab {
+    unsigned long long seg_total; // entries reserved by this pass's chunks (zeroed and folded into the frame total by the NEXT pass)
+    uint32_t ent_cursor;          // tile kernel: space handed out in the overflow arena of bins2 (zeroed by this pass's own binning)
+    uint32_t frame_no;
+};
+
+// A command (geometry pass or raster pass) carries a sequence number.  A pass that finds a work list too small raises
+// Counters::first_bad to its number (the smallest such number >= epoch wins; older values are stale); every kernel of a
+// LATER command, and the tile kernel of the failed command itself, then does nothing, so that the frame targets and the
+// tables hold exactly the state before the failed command.  The host sees the number at its next synchronisation point,
+// grows the list and replays the commands from there (frr_api.hip: finish) -- the caller never sees the overflow.
+constexpr uint32_t SEQ_NONE = 0xFFFFFFFFu;
+
+struct Counters {
+    uint32_t first_bad;     // see above
+    uint32_t overflow;      // bit0 fan capacity, bit1 bin capacity (which list to grow)
+    uint32_t totals_frame;  // the frame the totals below belong to
+    uint32_t pad0;
+    unsigned long long tot_frag_covered, tot_frag_nan, tot_bin_entries; // of the passes whose tables have been recycled
+    unsigned long long bin_total;     // (triangle,tile) pairs of the latest CSR binning
+    BinTab btab[2];
+    GeomTab gtab[2];
     // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py): funnel counters and per-phase wave cycles of the tile
     // kernel, in DBG_COPIES copies (workgroup b adds to copy b % DBG_COPIES: thousands of device atomics on one cache
     // line would serialise at ~17 ns each and distort what they measure); the host adds the copies up
     unsigned long long dbg[DBG_COPIES][24];
 };
+
+// has a command with sequence number `seq` been cancelled by an earlier failure?  (`own`: also by its own)
+__device__ __forceinline__ bool seq_cancelled(const Counters *cnt, uint32_t seq, uint32_t epoch, bool own)
+{
+    const uint32_t b = __hip_atomic_load(&cnt->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return b >= epoch && (own ? b <= seq : b < seq);
+}
+// a work list of command `seq` is too small (bits: which)
+__device__ __forceinline__ void seq_fail(Counters *cnt, uint32_t seq, uint32_t epoch, uint32_t bits)
+{
+    atomicOr(&cnt->overflow, bits);
+    uint32_t old = __hip_atomic_load(&cnt->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (old < epoch || old > seq) {
+        const uint32_t seen = atomicCAS(&cnt->first_bad, old, seq);
+        if (seen == old) break;
+        old = seen;
+    }
+}
 
 // ---- slots and order keys --------------------------------------------------------------------------------------
 // A draw's setup triangles live at SLOTS: input triangle t that emits exactly one triangle (the common, unclipped
@@ -99,12 +136,14 @@ struct GeomArgs {
     uint32_t ntris;
     uint32_t width, height; // viewport of renderer.rs:107-108
     uint32_t fan_cap;       // capacity of the fan space (triangles): FAN_REGIONS regions of fan_cap / FAN_REGIONS (a multiple of FAN_REGIONS)
-    int32_t reset_frame;    // first draw after frr_clear: the bookkeeping thread zeroes the frame counters first
+    uint32_t seq, epoch;    // sequence number of this geometry pass / failures before `epoch` are stale (Counters::first_bad)
+    uint32_t frame_no;      // frr_clear count: statistics are folded per frame (GeomTab::frame_no)
     int32_t part_rank, part_world; // tile-row ownership filter (world == 1: none); only set by frr_draw,
     int32_t part_y0, part_y1;      // which knows the raster window's height range
-    int32_t part_rpr;              // > 0: blocked partition (RasterArgs::rpr)
-    int32_t fslot;          // Counters::fan_cursor slot of this draw
-    uint32_t *block_sums;   // [nblocks] triangles emitted per 256-triangle block; scanned in place into Counters::block_prefix
+    int32_t part_blocked, part_brow0, part_brow1; // blocked partition: the rank owns tile rows [brow0, brow1) (RasterArgs)
+    int32_t gpar;           // parity of this pass: which Counters::gtab it fills
+    uint32_t *block_sums;   // [nblocks] triangles emitted per 256-triangle block
+    uint32_t *block_prefix; // [nblocks] their exclusive scan (geom_scan; a separate array: a replayed raster pass may scan again)
     uint32_t *tinfo;        // [ntris]   see Counters
     uint32_t *fanbase;      // [ntris]
     uint32_t *fan_okey;     // [fan_cap]
@@ -127,7 +166,7 @@ struct RasterArgs {
     int32_t tiles_x, tiles_y;
     uint32_t tiles_x_magic;           // 2^32 / tiles_x + 1: block index -> tile row by one multiplication (0: plain division)
     int32_t rank, world;              // tile-row ownership: ty % world == rank (interleaved), or ...
-    int32_t rpr;                      // ... rpr > 0: blocked, rank owns tile rows [rank*rpr, (rank+1)*rpr)
+    int32_t blocked, brow0, brow1;    // ... blocked != 0: the rank owns the contiguous tile rows [brow0, brow1)
     const RasterRec *recs;
     const float *vary;
     const uint4 *pbox;                // see GeomArgs::pbox
@@ -137,7 +176,10 @@ struct RasterArgs {
     uint32_t *tile_cursor;            // [ntiles]
     const uint32_t *seg;              // segmented binning: [nseg][ntiles+1] segment starts (+ end sentinel) into bins; nseg == 0: CSR (tile_offsets)
     uint32_t nseg;
-    int32_t slot;                     // which Counters::seg_total / ent_cursor slot this draw uses
+    int32_t bpar;                     // parity of this raster pass: which Counters::btab it uses
+    int32_t gpar;                     // parity of the geometry pass it rasterizes: which Counters::gtab it reads
+    uint32_t seq, epoch, frame_no;    // this raster pass's sequence number etc. (Counters::first_bad, GeomTab::frame_no)
+    uint32_t geom_seq;                // the geometry pass's number (its block-sum scan may ride in this pass's binning launch)
     int32_t fused_clear;              // this draw also performs the pending frr_clear for the tiles it owns:
     uint32_t clear_rgba;              //   keys start from clear_depth instead of the depth buffer and every pixel
     float clear_depth;                //   of the tile is written (full-window draws of the span kernel only)
@@ -156,33 +198,34 @@ struct RasterArgs {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
-// which rank rasterizes tile row ty (window-local): interleaved (rpr == 0) or blocks of rpr rows
-__device__ __forceinline__ bool owns_tile_row(int ty, int rank, int world, int rpr)
+// does this rank rasterize tile row ty (window-local)?  interleaved rows, or the block [brow0, brow1)
+struct RowOwner { int rank, world, blocked, brow0, brow1; };
+__device__ __forceinline__ bool owns_tile_row(int ty, const RowOwner &o)
 {
-    return world <= 1 || (rpr > 0 ? ty / rpr == rank : ty % world == rank);
+    return o.world <= 1 || (o.blocked ? (ty >= o.brow0 && ty < o.brow1) : ty % o.world == o.rank);
 }
 
 // Index of an OWNED tile row among the rank's rows (0, 1, 2 ...): the segmented binning and the tile kernel number a
 // rank's tiles row-major over its own rows only, so that a rank of N keeps 1/N of the tile counters, segment-table
 // columns and near-first slots.  (Rows the rank does not own may map anywhere: callers test ownership first.)
-__device__ __forceinline__ int local_tile_row(int ty, int rank, int world, int rpr)
+__device__ __forceinline__ int local_tile_row(int ty, const RowOwner &o)
 {
-    if (world <= 1) return ty;
-    if (rpr > 0) return ty - rank * rpr;
-    return (int)(((float)ty + 0.5f) * (1.0f / (float)world)); // ty / world: exact for tile rows (< 2^11)
+    if (o.world <= 1) return ty;
+    if (o.blocked) return ty - o.brow0;
+    return (int)(((float)ty + 0.5f) * (1.0f / (float)o.world)); // ty / world: exact for tile rows (< 2^11)
 }
 
 // The slots of the current draw as ONE virtual index range [0, total): the inputs' own slots, then the used part of fan
 // region 0, of region 1, ...  (what the binning kernels walk and split into chunks).
 struct FanMap { uint32_t ntris, region, pre[FAN_REGIONS + 1]; };   // pre[k]: used fan slots of the regions before k
-__device__ __forceinline__ FanMap fan_map(const Counters *cnt, int fslot, uint32_t fan_cap)
+__device__ __forceinline__ FanMap fan_map(const GeomTab *gt, uint32_t fan_cap)
 {
     FanMap m;
-    m.ntris = cnt->ntris_draw;
+    m.ntris = gt->ntris_draw;
     m.region = fan_cap / FAN_REGIONS;
     m.pre[0] = 0u;
 #pragma unroll
-    for (int k = 0; k < FAN_REGIONS; ++k) m.pre[k + 1] = m.pre[k] + min(cnt->fan_cursor[fslot][k].v, m.region);
+    for (int k = 0; k < FAN_REGIONS; ++k) m.pre[k + 1] = m.pre[k] + min(gt->fan_cursor[k].v, m.region);
     return m;
 }
 __device__ __forceinline__ uint32_t fan_map_total(const FanMap &m) { return m.ntris + m.pre[FAN_REGIONS]; }
@@ -199,25 +242,29 @@ __device__ __forceinline__ uint32_t fan_map_slot(const FanMap &m, uint32_t v)
     return m.ntris + k * m.region + (u - pk);
 }
 
-// what frr_clear does to the counters (by k_clear, or deferred to the next draw's bookkeeping thread)
-__device__ __forceinline__ void reset_frame_counters(Counters *cnt)
+// Frame statistics are kept per pass (GeomTab / BinTab) and folded into the totals when a table is recycled; a table
+// or a total of an older frame (frr_clear count) is simply dropped -- frr_clear itself touches nothing on the device.
+__device__ __forceinline__ void totals_for_frame(Counters *cnt, uint32_t frame_no)
 {
-    cnt->n_emit = 0; cnt->tri_base = 0; cnt->overflow = 0; cnt->bin_total = 0;
-    cnt->frag_covered = 0; cnt->frag_nan = 0; cnt->tris_in = 0; cnt->bin_entries_frame = 0; cnt->draws = 0;
-    cnt->skip_prev_bins = 1u;
-    // NOT the per-draw cursors (fan_cursor, seg_total, ent_cursor): the thread that calls this may run beside
-    // workgroups that are already allocating from the CURRENT draw's slot; the slots alternate per draw and every
-    // draw's kernels zero the OTHER slot for the draw after them
-    for (int j = 0; j < DBG_COPIES; ++j) for (int k = 0; k < 24; ++k) cnt->dbg[j][k] = 0;
+    if (cnt->totals_frame != frame_no) {
+        cnt->totals_frame = frame_no;
+        cnt->tot_frag_covered = 0ull; cnt->tot_frag_nan = 0ull; cnt->tot_bin_entries = 0ull;
+        for (int j = 0; j < DBG_COPIES; ++j) for (int k = 0; k < 24; ++k) cnt->dbg[j][k] = 0;
+    }
 }
 
-// the binning launch's bookkeeping (one thread): the other slot belongs to the previous draw, which has drained
-__device__ __forceinline__ void bin_bookkeeping(Counters *cnt, int slot)
+// the binning launch's bookkeeping (one thread).  The OTHER table belongs to the previous raster pass, whose binning has
+// drained (same stream): its total is folded and zeroed for the pass after this one.  (Its ent_cursor may still be in use
+// by that pass's tile kernel on the other stream: every pass zeroes its OWN before its tile kernel starts.)
+__device__ __forceinline__ void bin_bookkeeping(Counters *cnt, int bpar, uint32_t frame_no)
 {
-    if (!cnt->skip_prev_bins) cnt->bin_entries_frame += cnt->seg_total[slot ^ 1];
-    cnt->skip_prev_bins = 0u;
-    cnt->seg_total[slot ^ 1] = 0ull;
-    cnt->ent_cursor[slot ^ 1] = 0u;
+    totals_for_frame(cnt, frame_no);
+    BinTab &o = cnt->btab[bpar ^ 1];
+    if (o.frame_no == frame_no) cnt->tot_bin_entries += o.seg_total;
+    o.seg_total = 0ull;
+    o.frame_no = SEQ_NONE;
+    cnt->btab[bpar].ent_cursor = 0u;
+    cnt->btab[bpar].frame_no = frame_no;
 }
 
 // ---- glam pieces used by the shader table -------------------------------------
@@ -364,7 +411,7 @@ __device__ __forceinline__ bool tri_rows_owned(const GeomArgs &g, int iy0, int i
     const int maxy = clampi(max(iy0, max(iy1, iy2)), g.part_y0, g.part_y1);
     if (maxy <= miny) return false;
     const int ty0 = (miny - g.part_y0) / TILE, ty1 = (maxy - 1 - g.part_y0) / TILE;
-    if (g.part_rpr > 0) return ty0 < (g.part_rank + 1) * g.part_rpr && ty1 >= g.part_rank * g.part_rpr;
+    if (g.part_blocked) return ty0 < g.part_brow1 && ty1 >= g.part_brow0;
     const int first = ty0 + ((g.part_rank - ty0 % g.part_world) + g.part_world) % g.part_world;
     return first <= ty1;
 }

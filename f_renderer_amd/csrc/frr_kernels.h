@@ -13,8 +13,7 @@ namespace frr {
 // 16 B per lane streaming stores.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_clear(uint4 *__restrict__ color, uint4 *__restrict__ depth,
-                                               uint4 *__restrict__ ids, uint32_t n4, uint32_t rgba, float d,
-                                               Counters *cnt)
+                                               uint4 *__restrict__ ids, uint32_t n4, uint32_t rgba, float d)
 {
     const uint32_t db = f2u(d);
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
@@ -22,16 +21,15 @@ __global__ __launch_bounds__(256) void k_clear(uint4 *__restrict__ color, uint4 
         depth[i] = make_uint4(db, db, db, db);
         ids[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     }
-    if (cnt && blockIdx.x == 0 && threadIdx.x == 0) reset_frame_counters(cnt);
 }
 // the pixel rows of the tile rows a partitioned ctx does NOT own (they are skipped by a fused clear and
 // brought up to date only when somebody looks: frr_readback, frr_target_ptrs)
 __global__ __launch_bounds__(256) void k_clear_unowned_rows(uint32_t *__restrict__ color, uint32_t *__restrict__ depth,
-                                                            uint32_t *__restrict__ ids, uint32_t W, uint32_t H, int rank,
-                                                            int world, int rpr, uint32_t rgba, float d)
+                                                            uint32_t *__restrict__ ids, uint32_t W, uint32_t H, RowOwner own,
+                                                            uint32_t rgba, float d)
 {
     const uint32_t y = blockIdx.x;
-    if (y >= H || owns_tile_row((int)(y / TILE), rank, world, rpr)) return;
+    if (y >= H || owns_tile_row((int)(y / TILE), own)) return;
     for (uint32_t x = threadIdx.x; x < W; x += 256u) {
         const size_t i = (size_t)y * W + x;
         color[i] = rgba; depth[i] = f2u(d); ids[i] = ~0u;
@@ -122,12 +120,13 @@ template <bool SCATTER, class PUT>
 __device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, const uint4 pb, int lane, const PUT &put)
 {
     const uint32_t i = pb.w;    // the slot the entry stands for
+    const RowOwner own = {a.rank, a.world, a.blocked, a.brow0, a.brow1};
     const TileRange t = tiles_of_pbox(a, pb);
     const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
     const int nt = ntx * nty;
     auto visit = [&](const uint4 &ent, int tx, int ty) {
-        if (!owns_tile_row(ty, a.rank, a.world, a.rpr)) return;
-        const int tile = local_tile_row(ty, a.rank, a.world, a.rpr) * a.tiles_x + tx;
+        if (!owns_tile_row(ty, own)) return;
+        const int tile = local_tile_row(ty, own) * a.tiles_x + tx;
         if constexpr (SCATTER) {
             put(atomicAdd(&s_hist[tile], 1u), ent);
         } else {
@@ -141,10 +140,10 @@ __device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, c
     // predicated positions; 25.9 -> 23.0 us per launch on the 1080p frame without it.)
     const bool small = nt > 0 && ntx <= 2 && nty <= 2;
     if (small) {
-        const bool own0 = owns_tile_row(t.ty0, a.rank, a.world, a.rpr);
-        const bool own1 = nty == 2 && owns_tile_row(t.ty0 + 1, a.rank, a.world, a.rpr);
-        const int t00 = local_tile_row(t.ty0, a.rank, a.world, a.rpr) * a.tiles_x + t.tx0;
-        const int t10 = local_tile_row(t.ty0 + 1, a.rank, a.world, a.rpr) * a.tiles_x + t.tx0;
+        const bool own0 = owns_tile_row(t.ty0, own);
+        const bool own1 = nty == 2 && owns_tile_row(t.ty0 + 1, own);
+        const int t00 = local_tile_row(t.ty0, own) * a.tiles_x + t.tx0;
+        const int t10 = local_tile_row(t.ty0 + 1, own) * a.tiles_x + t.tx0;
         const bool v0 = own0, v1 = own0 && ntx == 2, v2 = own1, v3 = own1 && ntx == 2;
         if constexpr (SCATTER) {
             uint32_t p0 = ~0u, p1 = ~0u, p2 = ~0u, p3 = ~0u;
@@ -295,7 +294,7 @@ __device__ __forceinline__ uint32_t bin_scan_relative(uint32_t *s_hist, uint32_t
 // the workgroup's region of `bins`: ONE global atomic (by one thread; bin_cap when the frame overflowed, which flags it)
 __device__ __forceinline__ uint32_t bin_region_of(const RasterArgs &a, unsigned long long before, uint32_t total)
 {
-    if (before + total > (unsigned long long)a.bin_cap) { atomicOr(&a.cnt->overflow, 2u); return a.bin_cap; }
+    if (before + total > (unsigned long long)a.bin_cap) { seq_fail(a.cnt, a.seq, a.epoch, 2u); return a.bin_cap; }
     return (uint32_t)before;
 }
 
@@ -493,22 +492,26 @@ __device__ __forceinline__ SetupOut setup_unclipped(const float pos[3][4], const
     return o;
 }
 
-// per-draw bookkeeping, by ONE thread of the draw's geometry kernel.  It runs beside the kernel's other blocks, so it
-// touches nothing they touch: the fan cursor of THIS draw was zeroed by the draw before (every geometry path zeroes
-// the other slot -- the slots alternate per draw), and flags are raised only by later kernels (geom_scan, binning).
+// per-pass bookkeeping, by ONE thread of the pass's geometry kernel.  It runs beside the kernel's other blocks, so it
+// touches nothing they touch: the fan cursors of THIS pass's table were zeroed by the pass before (every geometry path
+// zeroes the other table's -- the tables alternate per pass), and flags are raised only by later kernels (geom_scan,
+// binning).  The table being recycled belongs to the pass two back, whose tile kernels have finished (the host orders
+// that with an event when the passes run on two streams): its fragment counts are folded into the frame totals.
 __device__ __forceinline__ void geom_bookkeeping(const GeomArgs &g)
 {
     Counters *cnt = g.cnt;
-    if (g.reset_frame) reset_frame_counters(cnt);
-    cnt->tri_base += cnt->n_emit;          // the previous draw's triangles precede this draw's (its block sums are scanned by now)
-    cnt->n_emit = 0u;
+    totals_for_frame(cnt, g.frame_no);
+    GeomTab &me = cnt->gtab[g.gpar], &prev = cnt->gtab[g.gpar ^ 1];
+    if (me.frame_no == g.frame_no) { cnt->tot_frag_covered += me.frag_covered; cnt->tot_frag_nan += me.frag_nan; }
+    me.frag_covered = 0ull; me.frag_nan = 0ull;
+    me.tri_base = prev.frame_no == g.frame_no ? prev.tri_base + prev.n_emit : 0u; // the previous pass's triangles precede this pass's (its block sums are scanned by now)
+    me.n_emit = 0u; me.need_fans = 0u;
+    me.frame_no = g.frame_no;
 #pragma unroll
-    for (int k = 0; k < FAN_REGIONS; ++k) cnt->fan_cursor[g.fslot ^ 1][k].v = 0u;
-    cnt->clip_q[g.fslot ^ 1] = 0u; cnt->clip_block_max[g.fslot ^ 1] = 0u;
-    cnt->ntris_draw = g.ntris;
-    cnt->tinfo = g.tinfo; cnt->fanbase = g.fanbase; cnt->fan_okey = g.fan_okey; cnt->block_prefix = g.block_sums;
-    cnt->tris_in += g.ntris;
-    cnt->draws += 1;
+    for (int k = 0; k < FAN_REGIONS; ++k) prev.fan_cursor[k].v = 0u;
+    prev.clip_q = 0u; prev.clip_block_max = 0u;
+    me.ntris_draw = g.ntris;
+    me.tinfo = g.tinfo; me.fanbase = g.fanbase; me.fan_okey = g.fan_okey; me.block_prefix = g.block_prefix;
 }
 
 template <int VS>
@@ -526,6 +529,8 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K;
     const uint32_t bid = blockIdx.x;
     const uint32_t t = bid * GEOM_BLOCK + threadIdx.x;
+    if (seq_cancelled(g.cnt, g.seq, g.epoch, false)) return;   // an earlier command failed: the host replays from there
+    GeomTab *const gt = &g.cnt->gtab[g.gpar];
     if (bid == 0 && threadIdx.x == 0) geom_bookkeeping(g);
     if (threadIdx.x == 0) s_ncl = 0; // ordered before its use by the barriers inside block_excl_scan256
     float pos[3][4];
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     uint32_t fbase_pending = 0u;
     if (threadIdx.x == 0) {
         g.block_sums[bid] = total;
-        if (ftotal) fbase_pending = atomicAdd(&g.cnt->fan_cursor[g.fslot][bid % FAN_REGIONS].v, ftotal);   // (within the block's region)
+        if (ftotal) fbase_pending = atomicAdd(&gt->fan_cursor[bid % FAN_REGIONS].v, ftotal);   // (within the block's region)
     }
     if (t < g.ntris) g.tinfo[t] = n | (eoff << FAN_BITS);
     if (fan_here) s_cl[atomicAdd(&s_ncl, 1u)] = threadIdx.x | (foff << 8);
@@ -668,10 +673,10 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
         // are, those blocks are the kernel's tail.  With the queue in use a block expands CLIP_INBLOCK of its own (one
         // per wave) and hands the rest to k_geom_clip.
         uint32_t nin = ncl;
-        if (threadIdx.x == 0 && ncl > (uint32_t)CLIP_QUEUE_AT) atomicMax(&g.cnt->clip_block_max[g.fslot], ncl);   // (few blocks: see above)
+        if (threadIdx.x == 0 && ncl > (uint32_t)CLIP_QUEUE_AT) atomicMax(&gt->clip_block_max, ncl);   // (few blocks: see above)
         if (g.use_clipq && ncl > (uint32_t)CLIP_INBLOCK) {
             nin = CLIP_INBLOCK;
-            if (threadIdx.x == 0) s_fbase = atomicAdd(&g.cnt->clip_q[g.fslot], ncl - nin);   // (s_fbase has been read by everyone)
+            if (threadIdx.x == 0) s_fbase = atomicAdd(&gt->clip_q, ncl - nin);   // (s_fbase has been read by everyone)
             __syncthreads();
             const uint32_t qb = s_fbase;
             for (uint32_t i = threadIdx.x; i < ncl - nin; i += GEOM_BLOCK) {
@@ -694,7 +699,8 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_clip(GeomArgs g, DevUniform
     __shared__ float s_cxy[GEOM_BLOCK / 64][CLIP_MAXV][2];
     __shared__ int32_t s_ckey[GEOM_BLOCK / 64][CLIP_MAXV];
     __shared__ float s_cv[GEOM_BLOCK / 64][CLIP_MAXV][7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)];
-    const uint32_t n = g.cnt->clip_q[g.fslot];
+    if (seq_cancelled(g.cnt, g.seq, g.epoch, false)) return;
+    const uint32_t n = g.cnt->gtab[g.gpar].clip_q;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t stride = gridDim.x * (GEOM_BLOCK / 64);
     for (uint32_t e = blockIdx.x * (GEOM_BLOCK / 64) + (uint32_t)w; e < n; e += stride) {
@@ -706,13 +712,14 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_clip(GeomArgs g, DevUniform
 // An empty mesh launches no geometry kernel proper: the per-draw bookkeeping alone.
 __global__ void k_geom_empty(GeomArgs g)
 {
+    if (seq_cancelled(g.cnt, g.seq, g.epoch, false)) return;
     if (threadIdx.x == 0 && blockIdx.x == 0) geom_bookkeeping(g);
 }
 
 // Exclusive scan of the draw's block sums (in place: they become Counters::block_prefix), by one workgroup of 1024
 // threads (the extra workgroup of k_bin_seg, or k_geom_scan on its own); publishes n_emit and raises the capacity flag
 // when the draw asked for more fan slots than there are.
-__device__ __forceinline__ void geom_scan(uint32_t *sums, uint32_t nblocks, Counters *cnt, int fslot, uint32_t fan_cap)
+__device__ __forceinline__ void geom_scan(const uint32_t *sums, uint32_t *prefix, uint32_t nblocks, Counters *cnt, int gpar, uint32_t fan_cap, uint32_t seq, uint32_t epoch)
 {
     __shared__ uint32_t s_sw[16];
     __shared__ uint32_t s_carry;
@@ -729,24 +736,26 @@ __device__ __forceinline__ void geom_scan(uint32_t *sums, uint32_t nblocks, Coun
 #pragma unroll
         for (int k = 0; k < 16; ++k) { uint32_t x = s_sw[k]; if (k < w) wbase += x; tot += x; }
         uint32_t carry = s_carry;
-        if (i < nblocks) sums[i] = carry + wbase + inc - v;
+        if (i < nblocks) prefix[i] = carry + wbase + inc - v;
         __syncthreads();
         if (threadIdx.x == 0) s_carry = carry + tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        cnt->n_emit = s_carry;
+        GeomTab &gt = cnt->gtab[gpar];
+        gt.n_emit = s_carry;
         uint32_t fans = 0;   // the fullest region decides: every region has fan_cap / FAN_REGIONS slots
 #pragma unroll
         for (int k = 0; k < FAN_REGIONS; ++k)
-            fans = max(fans, __hip_atomic_load(&cnt->fan_cursor[fslot][k].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        cnt->need_fans = fans * FAN_REGIONS;
-        if (fans > fan_cap / FAN_REGIONS) atomicOr(&cnt->overflow, 1u);
+            fans = max(fans, __hip_atomic_load(&gt.fan_cursor[k].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        gt.need_fans = fans * FAN_REGIONS;
+        if (fans > fan_cap / FAN_REGIONS) seq_fail(cnt, seq, epoch, 1u);
     }
 }
-__global__ __launch_bounds__(1024) void k_geom_scan(uint32_t *sums, uint32_t nblocks, Counters *cnt, int fslot, uint32_t fan_cap)
+__global__ __launch_bounds__(1024) void k_geom_scan(const uint32_t *sums, uint32_t *prefix, uint32_t nblocks, Counters *cnt, int gpar, uint32_t fan_cap, uint32_t seq, uint32_t epoch)
 {
-    geom_scan(sums, nblocks, cnt, fslot, fan_cap);
+    if (seq_cancelled(cnt, seq, epoch, false)) return;
+    geom_scan(sums, prefix, nblocks, cnt, gpar, fan_cap, seq, epoch);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -757,9 +766,10 @@ __global__ __launch_bounds__(1024) void k_geom_scan(uint32_t *sums, uint32_t nbl
 constexpr int BIN_COOP = 6;
 
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_bin(RasterArgs a, int fslot, uint32_t fan_cap)
+__global__ __launch_bounds__(256) void k_bin(RasterArgs a, uint32_t fan_cap)
 {
-    const FanMap fm = fan_map(a.cnt, fslot, fan_cap);
+    if (seq_cancelled(a.cnt, a.seq, a.epoch, false)) return;
+    const FanMap fm = fan_map(&a.cnt->gtab[a.gpar], fan_cap);
     const uint32_t n = fan_map_total(fm);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6);
@@ -768,11 +778,12 @@ __global__ __launch_bounds__(256) void k_bin(RasterArgs a, int fslot, uint32_t f
         // entry index: the inputs' entries (dense per block, zero = nothing, GeomArgs::pbox), then the used fan entries
         const uint4 cu = base + lane < n ? a.pbox[fan_map_slot(fm, base + lane)] : make_uint4(0u, 0u, 0u, 0u); // (0,0)-(0,0) is an empty box
         const uint32_t i = cu.w;   // the slot the entry stands for
+        const RowOwner own = {a.rank, a.world, a.blocked, a.brow0, a.brow1};
         const TileRange t = tiles_of_pbox(a, cu);
         const int ntx = t.tx1 - t.tx0, nty = t.ty1 - t.ty0;
         const int nt = ntx * nty;
         auto visit = [&](const uint4 &ent, int tx, int ty) {
-            if (!owns_tile_row(ty, a.rank, a.world, a.rpr)) return;
+            if (!owns_tile_row(ty, own)) return;
             const int tile = ty * a.tiles_x + tx;
             if constexpr (FILL) {
                 uint32_t pos = a.tile_offsets[tile] + atomicAdd(&a.tile_cursor[tile], 1u);
@@ -802,6 +813,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(RasterArgs a, uint32_t ntile
 {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
+    if (seq_cancelled(a.cnt, a.seq, a.epoch, false)) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
@@ -824,8 +836,9 @@ __global__ __launch_bounds__(1024) void k_tile_scan(RasterArgs a, uint32_t ntile
         uint32_t total = s_carry;
         a.tile_offsets[ntiles] = total;
         a.cnt->bin_total = total;
-        a.cnt->bin_entries_frame += total;
-        if (total > a.bin_cap) a.cnt->overflow |= 2u;
+        totals_for_frame(a.cnt, a.frame_no);
+        if (total > a.bin_cap) seq_fail(a.cnt, a.seq, a.epoch, 2u);
+        else a.cnt->tot_bin_entries += total;
     }
 }
 
@@ -844,22 +857,23 @@ __global__ __launch_bounds__(1024) void k_tile_scan(RasterArgs a, uint32_t ntile
 // as the fallback when the tile count does not fit LDS.
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg, int slot,
-                                                    uint32_t stage_cap, int fslot, uint32_t fan_cap, uint32_t *block_sums, uint32_t nblocks, int do_scan)
+__global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg,
+                                                    uint32_t stage_cap, uint32_t fan_cap, const uint32_t *block_sums, uint32_t *block_prefix, uint32_t nblocks, int do_scan)
 {
+    if (seq_cancelled(a.cnt, a.seq, a.epoch, false)) return;
     // do_scan: the launch's LAST workgroup scans the geometry kernel's block sums instead (the tile kernel's resolve
     // needs the prefix for triangle ids; here it costs no launch and sits on nobody's critical path)
-    if (do_scan && blockIdx.x == gridDim.x - 1) { geom_scan(block_sums, nblocks, a.cnt, fslot, fan_cap); return; }
+    if (do_scan && blockIdx.x == gridDim.x - 1) { geom_scan(block_sums, block_prefix, nblocks, a.cnt, a.gpar, fan_cap, a.geom_seq, a.epoch); return; }
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[]; // [ntiles], then the staging records
     uint4 *s_stage = reinterpret_cast<uint4 *>(s_hist + ((ntiles + 3u) & ~3u));
     __shared__ uint32_t s_w[2][BIN_WG / 64];
     __shared__ uint32_t s_base;
     const uint32_t g = blockIdx.x, G = gridDim.x - (uint32_t)do_scan;
     for (uint32_t t = threadIdx.x; t < ((ntiles + 3u) & ~3u); t += BIN_WG) s_hist[t] = 0u;   // (padded to four: bin_scan_relative)
-    if (g == 0 && threadIdx.x == 0) bin_bookkeeping(a.cnt, slot);
+    if (g == 0 && threadIdx.x == 0) bin_bookkeeping(a.cnt, a.bpar, a.frame_no);
     __syncthreads();
     // a workgroup's chunk: a range of geometry blocks (their dense entries) and a range of the used fan entries
-    const FanMap fm = fan_map(a.cnt, fslot, fan_cap);
+    const FanMap fm = fan_map(&a.cnt->gtab[a.gpar], fan_cap);
     const uint32_t bpw = (nblocks + G - 1) / G;
     const uint32_t b_lo = min(nblocks, g * bpw), b_hi = min(nblocks, b_lo + bpw);
     const uint32_t nfan = fm.pre[FAN_REGIONS];
@@ -885,7 +899,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     // the region is reserved now, but only a workgroup whose records do not all fit the LDS staging has to know where it
     // starts before it places them: the others walk while the atomic is in flight
     unsigned long long before = 0;
-    if (threadIdx.x == 0) before = atomicAdd(&a.cnt->seg_total[slot], (unsigned long long)total);
+    if (threadIdx.x == 0) before = atomicAdd(&a.cnt->btab[a.bpar].seg_total, (unsigned long long)total);
     uint32_t base = 0;
     if (total > stage_cap) {
         if (threadIdx.x == 0) s_base = bin_region_of(a, before, total);

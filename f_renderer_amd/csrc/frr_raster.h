@@ -31,18 +31,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 
 // ---- order keys <-> slots <-> emission indices of the current draw (frr_device.h: slots and order keys) -------------
 // low half of a pixel key for the triangle at `slot`: order key + 1 (0 = "what was there before this draw")
-__device__ __forceinline__ uint32_t order_id(const Counters *cnt, uint32_t slot)
+__device__ __forceinline__ uint32_t order_id(const GeomTab *cnt, uint32_t slot)
 {
     const uint32_t nt = cnt->ntris_draw;
     return 1u + (slot < nt ? slot << FAN_BITS : cnt->fan_okey[slot - nt]);
 }
 // the slot a winning id of THIS draw names, and the reference's emission index of that triangle within the frame
-__device__ __forceinline__ uint32_t id_slot(const Counters *cnt, uint32_t id)
+__device__ __forceinline__ uint32_t id_slot(const GeomTab *cnt, uint32_t id)
 {
     const uint32_t okl = id - 1u, t = okl >> FAN_BITS, f = okl & ((1u << FAN_BITS) - 1u);
     return f ? cnt->ntris_draw + cnt->fanbase[t] + (f - 1u) : t;
 }
-__device__ __forceinline__ uint32_t id_emission(const Counters *cnt, uint32_t id)
+__device__ __forceinline__ uint32_t id_emission(const GeomTab *cnt, uint32_t id)
 {
     const uint32_t okl = id - 1u, t = okl >> FAN_BITS, f = okl & ((1u << FAN_BITS) - 1u);
     return cnt->tri_base + cnt->block_prefix[t / GEOM_BLOCK] + (cnt->tinfo[t] >> FAN_BITS) + (f ? f - 1u : 0u);
@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t id_emission(const Counters *cnt, uint32_t id
 // Depth-only draws keep  emission index (within the draw) + 1  in their pixel keys instead of the order key: it is
 // just as monotone, the lookups below are then paid once per surviving triangle of a tile instead of once per pixel,
 // and the resolve adds tri_base.  (Shaded draws need the winner's SLOT per pixel, which only the order key gives.)
-__device__ __forceinline__ uint32_t emission_id(const Counters *cnt, uint32_t slot)
+__device__ __forceinline__ uint32_t emission_id(const GeomTab *cnt, uint32_t slot)
 {
     const uint32_t nt = cnt->ntris_draw;
     uint32_t t = slot, q = 0u;
@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t emission_id(const Counters *cnt, uint32_t sl
 }
 // the slot of the triangle with emission index e (within the draw): two binary searches; only the depth-only resolve's
 // rare re-evaluation (-0.0 / NaN depths) needs it
-__device__ __forceinline__ uint32_t slot_of_emission(const Counters *cnt, uint32_t e)
+__device__ __forceinline__ uint32_t slot_of_emission(const GeomTab *cnt, uint32_t e)
 {
     const uint32_t nt = cnt->ntris_draw, nb = (nt + GEOM_BLOCK - 1) / GEOM_BLOCK;
     uint32_t lo = 0, hi = nb;                       // last block whose prefix <= e
@@ -74,6 +74,8 @@ __device__ __forceinline__ uint32_t slot_of_emission(const Counters *cnt, uint32
     return n == 1u ? a : nt + cnt->fanbase[a] + q;
 }
 
+__device__ __forceinline__ const GeomTab *gtab_of(const RasterArgs &a) { return &a.cnt->gtab[a.gpar]; }
+
 struct TileCtx {
     int tile, ltile, lx0, ly0, tw, th, ax0, ay0; // tile index in the window / among the rank's own tiles; window-local origin, extent, absolute pixel origin
     uint32_t beg, end;
@@ -86,7 +88,7 @@ __device__ __forceinline__ TileCtx tile_ctx(const RasterArgs &a)
     // bid / tiles_x by multiplication (scalar unit): exact for bid, tiles_x < 2^16 (tiles_x_magic = 2^32 / tiles_x + 1; 0: divide)
     const int trow = a.tiles_x_magic ? (int)__builtin_amdgcn_readfirstlane((int)__umulhi((uint32_t)bid, a.tiles_x_magic)) : bid / a.tiles_x;
     const int tx = bid - trow * a.tiles_x;
-    const int ty = a.rpr > 0 ? a.rank * a.rpr + trow : a.rank + trow * a.world;
+    const int ty = a.blocked ? a.brow0 + trow : a.rank + trow * a.world;
     c.tile = ty * a.tiles_x + tx;
     c.ltile = bid;                                      // its index among the rank's own tiles (segmented binning)
     c.lx0 = tx * TILE; c.ly0 = ty * TILE;
@@ -151,7 +153,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
             if (id == 0u) { a.depth[pi] = a.clear_depth; a.tri_id[pi] = ~0u; }
         }
         if (id == 0u) continue; // existing depth won (or nothing covered this pixel)
-        const uint32_t t = id_slot(a.cnt, id);
+        const uint32_t t = id_slot(gtab_of(a), id);
         if constexpr (PS == FRR_PS_DEPTH) {
             // depth only: the z key is an invertible image of rhw except that it merges -0.0 with +0.0
             // (and NaNs are not ordered): those two cases are re-evaluated below, everything else is decoded
@@ -159,7 +161,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
             if (dz != 0.0f && dz == dz) {
                 const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
                 a.depth[di] = dz;                                                   // :366
-                a.tri_id[di] = id_emission(a.cnt, id);
+                a.tri_id[di] = id_emission(gtab_of(a), id);
                 continue;
             }
         }
@@ -170,7 +172,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
         Frag f = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), r0, r1, r2, cx, cy);
         const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
         a.depth[di] = f.rhw;                                                    // :366
-        a.tri_id[di] = id_emission(a.cnt, id);
+        a.tri_id[di] = id_emission(gtab_of(a), id);
         if constexpr (PS != FRR_PS_DEPTH) {
             const float w = recip_exact(f.rhw != 0.0f ? f.rhw : 1.0f);          // :368 (== 1.0f / x, bit for bit)
             const float c0 = r0 * f.a * w, c1 = r1 * f.b * w, c2 = r2 * f.c * w; // :370-372
@@ -196,7 +198,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
 __device__ __forceinline__ void tile_resolve_depth4(const RasterArgs &a, const TileCtx &c, const unsigned long long *s_key)
 {
     const bool fused = a.fused_clear != 0;
-    const uint32_t tri_base = a.cnt->tri_base;      // (the keys of a depth-only draw hold emission indices: emission_id)
+    const uint32_t tri_base = gtab_of(a)->tri_base;      // (the keys of a depth-only draw hold emission indices: emission_id)
     for (int g = threadIdx.x; g < TILE_PX / 4; g += (int)blockDim.x) {
         const int y = g >> 3, x = (g & 7) * 4;
         if (y >= c.th || x >= c.tw) continue;
@@ -209,7 +211,7 @@ __device__ __forceinline__ void tile_resolve_depth4(const RasterArgs &a, const T
             won[i] = id[i] != 0u && x + i < c.tw;      // (pixels of a partial tile beyond the window hold all-ones keys)
             float dz = zkey_decode(zk[i]);
             if (won[i] && !(dz != 0.0f && dz == dz)) { // -0.0 merged with +0.0, or NaN: the reference arithmetic decides
-                const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + slot_of_emission(a.cnt, id[i] - 1u));
+                const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + slot_of_emission(gtab_of(a), id[i] - 1u));
                 const uint4 q1 = rp[1], q2 = rp[2], q3 = rp[3];
                 dz = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y), u2f(q3.z),
                                c.ax0 + x + i, c.ay0 + y).rhw;
@@ -331,6 +333,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
     __shared__ unsigned long long s_key[TILE_PX];
     __shared__ uint32_t s_nanL[TILE_PX];
     __shared__ uint32_t s_nanflag;
+    if (seq_cancelled(a.cnt, a.seq, a.epoch, true)) return; // this or an earlier command failed: the targets stay as they are, the host replays
     const TileCtx c = tile_ctx(a);
     if (c.beg >= c.end) return; // nothing binned here: colour, depth and ids stay as they are
     tile_load_keys(a, c, s_key);
@@ -341,17 +344,17 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
     uint32_t n_cov = 0, n_nan = 0;
     for (uint32_t e = c.beg + wave; e < c.end; e += 4) {
         const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e].x);
-        sweep_triangle(a, c, t, order_id(a.cnt, t), lane, s_key, n_cov, n_nan, &s_nanflag);
+        sweep_triangle(a, c, t, order_id(gtab_of(a), t), lane, s_key, n_cov, n_nan, &s_nanflag);
     }
-    if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
-    if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
+    if (lane == 0 && n_cov) atomicAdd(&a.cnt->gtab[a.gpar].frag_covered, (unsigned long long)n_cov);
+    if (n_nan) atomicAdd(&a.cnt->gtab[a.gpar].frag_nan, (unsigned long long)n_nan);
     __syncthreads();
     if (s_nanflag != 0u) { // (uniform: read after the barrier)
         tile_nan_begin(c, s_key, s_nanL);
         __syncthreads();
         for (uint32_t e = c.beg + wave; e < c.end; e += 4) {
             const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e].x);
-            sweep_triangle<true>(a, c, t, order_id(a.cnt, t), lane, s_key, n_cov, n_nan, nullptr, s_nanL);
+            sweep_triangle<true>(a, c, t, order_id(gtab_of(a), t), lane, s_key, n_cov, n_nan, nullptr, s_nanL);
         }
         __syncthreads();
     }
@@ -577,6 +580,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
 #else
 #define FRR_T(i) do { } while (0)
 #endif
+    if (seq_cancelled(a.cnt, a.seq, a.epoch, true)) return; // this or an earlier command failed: the targets stay as they are, the host replays
     TileCtx c = tile_ctx(a);
     const bool segmented = a.nseg != 0;
     if (segmented) {
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             // single address costs ~17 ns each, serialised across the whole launch; hence the slots.)
             const uint32_t ntiles = gridDim.x;
             s_ebase = total <= a.ent_slot ? (uint32_t)c.ltile * a.ent_slot
-                                          : ntiles * a.ent_slot + atomicAdd(&a.cnt->ent_cursor[a.slot], total);
+                                          : ntiles * a.ent_slot + atomicAdd(&a.cnt->btab[a.bpar].ent_cursor, total);
         }
         __syncthreads();
         c.beg = __builtin_amdgcn_readfirstlane(s_ebase); // this tile's range of the near-first copy (bins2)
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             um &= um - 1;
             const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)en.x, src);
             uint32_t ncv = 0;
-            sweep_triangle(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(a.cnt, tu) : order_id(a.cnt, tu), lane, s_key, ncv, n_nan, &s_nanflag);
+            sweep_triangle(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(gtab_of(a), tu) : order_id(gtab_of(a), tu), lane, s_key, ncv, n_nan, &s_nanflag);
             n_cov += ncv;
         }
         const unsigned long long am = __ballot(alive);
@@ -827,7 +831,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             s_tri[w][trank] = t;
             s_fa[w][trank] = make_float4(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y));
             s_fb[w][trank] = make_float4(u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y));
-            s_fc[w][trank] = make_float2(u2f(q3.z), u2f(PS == FRR_PS_DEPTH ? emission_id(a.cnt, en.x) : order_id(a.cnt, en.x)));
+            s_fc[w][trank] = make_float2(u2f(q3.z), u2f(PS == FRR_PS_DEPTH ? emission_id(gtab_of(a), en.x) : order_id(gtab_of(a), en.x)));
         }
         // rows of all survivors laid end to end: heads mark where each triangle's rows start
         const uint32_t rincl = wave_incl_scan_dpp(rows);
@@ -947,7 +951,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         wave_lds_fence(); // staging is rewritten by the next step
     }
     FRR_T(1);
-    if (lane == 0 && n_cov) atomicAdd((unsigned long long *)&a.cnt->frag_covered, (unsigned long long)n_cov);
+    if (lane == 0 && n_cov) atomicAdd(&a.cnt->gtab[a.gpar].frag_covered, (unsigned long long)n_cov);
 #ifdef FRR_DEBUG_COUNTERS
     d_rt2 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
@@ -958,7 +962,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         atomicAdd(d + 8, (unsigned long long)d_pre); atomicAdd(d + 9, (unsigned long long)d_win); atomicAdd(d + 10, (unsigned long long)d_rebuild);
     }
 #endif
-    if (n_nan) atomicAdd((unsigned long long *)&a.cnt->frag_nan, (unsigned long long)n_nan);
+    if (n_nan) atomicAdd(&a.cnt->gtab[a.gpar].frag_nan, (unsigned long long)n_nan);
     __syncthreads();
     if (s_nanflag != 0u) {
         // NaN fragments (renderer.rs:363-366): the pixels they cover are decided by a second, unculled sweep of ALL the
@@ -972,12 +976,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
                 const int src = __builtin_ctzll(m);
                 m &= m - 1;
                 const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)dent.x, src);
-                sweep_triangle<true>(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(a.cnt, tu) : order_id(a.cnt, tu), lane, s_key, dummy_cov, dummy_nan, nullptr, s_nanL);
+                sweep_triangle<true>(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(gtab_of(a), tu) : order_id(gtab_of(a), tu), lane, s_key, dummy_cov, dummy_nan, nullptr, s_nanL);
             }
         } else {
             for (uint32_t e = c.beg + (uint32_t)w; e < c.end; e += NW) {
                 const uint32_t tu = __builtin_amdgcn_readfirstlane(ents[e].x);
-                sweep_triangle<true>(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(a.cnt, tu) : order_id(a.cnt, tu), lane, s_key, dummy_cov, dummy_nan, nullptr, s_nanL);
+                sweep_triangle<true>(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(gtab_of(a), tu) : order_id(gtab_of(a), tu), lane, s_key, dummy_cov, dummy_nan, nullptr, s_nanL);
             }
         }
         __syncthreads();

@@ -81,46 +81,76 @@ class BandGather:
         return None
 
 
+def block_tile_rows(tiles_y, rank, world):
+    """Tile rows [t0, t1) of `rank` in the blocked layout (frr_set_partition_layout(1), frr_owned_rows): tiles_y // world
+    rows each, the first tiles_y % world ranks one more -- no rank of world <= tiles_y is left without rows."""
+    q, r = divmod(tiles_y, world)
+    t0 = rank * q + min(rank, r)
+    return t0, t0 + q + (1 if rank < r else 0)
+
+
 def block_rows(height, rank, world):
     """Pixel rows [y0, y1) of the padded image that `rank` owns in the blocked layout."""
-    _, rows_per_rank, _ = band_layout(height, world)
-    return rank * rows_per_rank * TILE, (rank + 1) * rows_per_rank * TILE
+    tiles_y = (height + TILE - 1) // TILE
+    t0, t1 = block_tile_rows(tiles_y, rank, world)
+    return t0 * TILE, t1 * TILE
+
+
+def tile_row_owner(tiles_y, world, blocked):
+    """owner[ty] = the rank that rasterizes tile row ty (both layouts): what tests and tools stitch partial images with."""
+    if not blocked:
+        return [ty % world for ty in range(tiles_y)]
+    owner = [0] * tiles_y
+    for rank in range(world):
+        t0, t1 = block_tile_rows(tiles_y, rank, world)
+        for ty in range(t0, t1):
+            owner[ty] = rank
+    return owner
 
 
 class BlockGather:
-    """Blocked layout: rank r owns the contiguous pixel rows block_rows(height, r, world) of the padded
-    image, so its slab is gathered straight from the render target into the final image on `dst`."""
+    """Blocked layout: rank r owns the contiguous pixel rows block_rows(height, r, world) of the padded image, so its
+    slab goes straight from the render target into the final image on `dst`: one send per rank, the receives on `dst`
+    posted into views of the final image, all in ONE group (ncclGroupStart/End under torch.distributed's "nccl"
+    backend) -- the slabs differ by a tile row when the rows do not divide evenly, so this is send/recv, not a gather
+    of equal parts.  The native form of the same exchange: examples/gather_rccl.cpp."""
 
     def __init__(self, height, width, dtype, device, rank, world, dst=0, trailing=()):
-        self.rank, self.world, self.dst = rank, world, dst
-        _, self.rows_per_rank, self.padded_height = band_layout(height, world)
-        self.slab = self.rows_per_rank * TILE
-        if rank == dst:
-            self.final = torch.zeros((self.padded_height, width, *trailing), dtype=dtype, device=device)
-            self.gathered = list(self.final.view(world, self.slab, width, *trailing).unbind(0))  # contiguous views
-        else:
-            self.final, self.gathered = None, None
+        self.rank, self.world, self.dst, self.height = rank, world, dst, height
+        _, _, self.padded_height = band_layout(height, world)
+        self.y0, self.y1 = block_rows(height, rank, world)
+        self.final = torch.zeros((self.padded_height, width, *trailing), dtype=dtype, device=device) if rank == dst else None
 
     def start(self, local_image, group=None):
-        """Launches the gather of this rank's slab of `local_image` ([HP, W, ...]) without waiting for it."""
+        """Launches the exchange of this rank's slab of `local_image` ([HP, W, ...]) without waiting for it."""
         import torch.distributed as dist
-        y0, y1 = self.rank * self.slab, (self.rank + 1) * self.slab
-        return dist.gather(local_image[y0:y1], self.gathered, dst=self.dst, group=group, async_op=True)
+        ops = []
+        if self.rank == self.dst:
+            self.final[self.y0:self.y1].copy_(local_image[self.y0:self.y1])
+            for r in range(self.world):
+                a, b = block_rows(self.height, r, self.world)
+                if r != self.dst and b > a:
+                    ops.append(dist.P2POp(dist.irecv, self.final[a:b], r, group))
+        elif self.y1 > self.y0:
+            ops.append(dist.P2POp(dist.isend, local_image[self.y0:self.y1], self.dst, group))
+        return dist.batch_isend_irecv(ops) if ops else []
 
-    def finish(self, handle):
-        handle.wait()
+    def finish(self, handles):
+        for h in handles:
+            h.wait()
         return self.final
 
-    def finish_host(self, handle):
+    def finish_host(self, handles):
         """Like finish(), but the HOST polls for completion instead of making the current stream wait: with enough
-        target sets in flight the gather has long completed, and the render stream carries no dependency packet
+        target sets in flight the exchange has long completed, and the render stream carries no dependency packet
         (a stream-side wait costs the 150-us frame several microseconds even when it is already satisfied)."""
         import time
         t0 = time.perf_counter()
-        while not handle.is_completed():
-            if time.perf_counter() - t0 > 2.0:   # never expected; fall back to the stream-side wait rather than spin forever
-                handle.wait()
-                break
+        for h in handles:
+            while not h.is_completed():
+                if time.perf_counter() - t0 > 2.0:   # never expected; fall back to the stream-side wait rather than spin forever
+                    h.wait()
+                    break
         return self.final
 
     def __call__(self, local_image, group=None):
@@ -142,7 +172,7 @@ class FrameGather:
         return [p.start(img, group) for p, img in zip(self.parts, images)]
 
     def finish(self, handles):
-        return [p.finish(h) for p, h in zip(self.parts, handles)]
+        return [p.finish(h) for p, h in zip(self.parts, handles)]   # (None on ranks other than dst)
 
     def finish_host(self, handles):
         return [p.finish_host(h) for p, h in zip(self.parts, handles)]

@@ -118,7 +118,8 @@ def _options_from_env():
     if e.get("FRR_RASTER") == "sweep":
         o["raster_sweep"] = 1
     for var, name in (("FRR_RASTER_NW", "raster_nw"), ("FRR_RASTER_OCC", "raster_occ"), ("FRR_BIN_G", "bin_chunks"),
-                      ("FRR_ENT_SLOT", "tile_slot_records"), ("FRR_BIN_CAP", "bin_capacity"), ("FRR_CLIP_QUEUE", "clip_queue")):
+                      ("FRR_ENT_SLOT", "tile_slot_records"), ("FRR_BIN_CAP", "bin_capacity"), ("FRR_FAN_CAP", "fan_capacity"),
+                      ("FRR_CLIP_QUEUE", "clip_queue"), ("FRR_OVERLAP", "overlap")):
         if e.get(var):
             o[name] = int(e[var])
     if e.get("FRR_CLEAR") == "eager":
@@ -222,7 +223,7 @@ class Renderer:
 
     def set_partition(self, rank, world, blocked=False):
         """Tile-row ownership of a multi-GPU rank: interleaved rows (ty % world == rank) or, blocked=True,
-        the contiguous rows [rank*k, (rank+1)*k), k = ceil(tile_rows / world)."""
+        a contiguous run of tile_rows // world rows (the first tile_rows % world ranks one more)."""
         self._check(self._lib.frr_set_partition(self._ctx, rank, world))
         self._check(self._lib.frr_set_partition_layout(self._ctx, 1 if blocked else 0))
 

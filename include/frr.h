@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FRR_ABI_VERSION 2
+#define FRR_ABI_VERSION 3
 #define FRR_MAX_VARYINGS 16
 #define FRR_MAX_TEXTURES 4
 #define FRR_MAX_OUT_TRIS 19 /* 3 + 18 clip vertices -> 19 fan triangles (renderer.rs:150-171,245-264) */
@@ -39,8 +39,11 @@ typedef enum frr_status {
     FRR_ERR_HIP = -2,         /* HIP runtime error / no gfx950 device; see frr_last_error */
     FRR_ERR_NOMEM = -3,
     FRR_ERR_UNSUPPORTED = -4,
-    FRR_ERR_CAPACITY = -5     /* a device work list overflowed during the frame; the ctx has grown
-                                 it, re-issue the frame (reported by frr_sync/frr_readback/frr_stats) */
+    FRR_ERR_CAPACITY = -5     /* not something a caller has to handle: a device work list (fan slots, (triangle, tile)
+                                 records) that turns out too small is grown and the commands since the failing one are
+                                 replayed INSIDE the library at the next synchronisation point (frr_sync, frr_readback,
+                                 frr_get_stats ...) -- Renderer::rasterization cannot fail (renderer.rs:269-384), neither
+                                 can frr_draw.  This code is returned only if eight replays in a row were not enough. */
 } frr_status;
 
 /* Vertex-shader table.  Replaces the `vertex_shader: &F` closure argument (renderer.rs:105,110). */
@@ -92,14 +95,20 @@ typedef struct frr_stats {
                               fragment on their pixel (renderer.rs:363-366): reproduced exactly, by a second pass over the
                               tiles that saw one (the NaN bit pattern itself is the device's) */
     uint32_t draws;
-    uint32_t overflow;     /* non-zero => this frame is invalid, see FRR_ERR_CAPACITY */
+    uint32_t replays;      /* how often the library had to grow a work list and replay commands of this frame (see
+                              FRR_ERR_CAPACITY): a diagnostic, the results are those of a frame that never failed */
 } frr_stats;
 
 /* ---- context ------------------------------------------------------------------------------ */
 
 /* Creates a context on HIP device `device` with a width x height FrameBuffer (renderer.rs:419-425),
  * an f32 depth buffer (phong.rs:208) and a u32 triangle-id buffer.  `stream` is a hipStream_t the
- * caller owns (e.g. torch's current stream), or NULL for a private stream. */
+ * caller owns (e.g. torch's current stream), or NULL for a private stream: everything that touches the frame targets
+ * (tile kernels, clears, read-backs) runs on it, in call order.  The ctx owns a second, private stream on which the
+ * geometry and binning kernels of the next draw run beside the tile kernel of the current one (option "overlap");
+ * it is ordered against `stream` with events, so the caller sees one in-order queue -- with one rule: the contents of
+ * a device-bound mesh (frr_mesh_bind_device) are read some time between the frr_draw call and the draw's tile kernel,
+ * so a caller that rewrites such a mesh in place on `stream` binds it again (or calls frr_sync) before the next draw. */
 int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ctx **out);
 void frr_destroy(frr_ctx *ctx);
 const char *frr_last_error(const frr_ctx *ctx);
@@ -109,9 +118,9 @@ int frr_abi_version(void);
  * ty % world == rank (geometry is replicated).  Default (0,1) = everything. */
 int frr_set_partition(frr_ctx *ctx, int rank, int world);
 /* Which tile rows a rank owns: 0 (default) = interleaved, ty % world == rank -- balances scenes whose
- * load varies down the screen; 1 = blocked, rank owns the contiguous rows [rank*k, (rank+1)*k) with
- * k = ceil(tile_rows / world) -- its part of a row-major image is then ONE contiguous slab, so the
- * final-image gather needs no staging copies (bench.py uses this). */
+ * load varies down the screen; 1 = blocked, rank owns a contiguous run of tile_rows / world rows, the first
+ * tile_rows % world ranks one more (34 rows over 8 ranks: 5,5,4,4,4,4,4,4; frr_owned_rows tells) -- its part of a
+ * row-major image is then ONE contiguous slab, so the final-image gather needs no staging copies (bench.py uses this). */
 int frr_set_partition_layout(frr_ctx *ctx, int blocked);
 /* The pixel rows of a raster window height_range = (y0, y1) (renderer.rs:271: the sub-window argument this whole
  * partition rests on) that this rank owns, as bands [row0, row1) of window-local rows: ONE band in the blocked
@@ -157,8 +166,7 @@ int frr_vs_num_varyings(int vs_id);
  * work is deferred: the next full-framebuffer frr_raster / frr_draw performs the clear inside its tile
  * kernel; every other call that can observe the targets or the statistics (frr_readback, frr_sync,
  * frr_get_stats, frr_target_ptrs, frr_bind_targets, a sub-window raster) settles it first, so the
- * observable behaviour is that of an immediate clear.  (FRR_CLEAR=eager in the environment makes it
- * immediate.) */
+ * observable behaviour is that of an immediate clear.  (Option clear_eager makes it immediate.) */
 int frr_clear(frr_ctx *ctx, const uint8_t rgba[4], float depth);
 
 /* Loop A (phong.rs:321-331): Renderer::geometry_processing over every input triangle of `mesh`,
@@ -177,6 +185,9 @@ int frr_raster(frr_ctx *ctx, int ps_id, int32_t x0, int32_t x1, int32_t y0, int3
  * frr_readback_setup. */
 int frr_draw(frr_ctx *ctx, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1);
 
+/* Synchronisation point: waits for everything issued so far (both streams).  Caller-bound targets are defined, and a
+ * draw that needed a larger work list has been replayed (FRR_ERR_CAPACITY), when this -- or frr_readback,
+ * frr_get_stats, frr_readback_setup, frr_geometry with a count -- returns. */
 int frr_sync(frr_ctx *ctx);
 /* FrameBuffer::get_data (renderer.rs:473-475) + depth + triangle ids -> host; NULLs skipped.
  * tri_id holds, per depth-buffer index, the global emission index (over the draws since the last
@@ -198,7 +209,10 @@ int frr_event_elapsed_ms(frr_ctx *ctx, int a, int b, float *ms);
  *                             (4, 6, 8); 0 = chosen per launch
  *   "bin_chunks"              number of chunk workgroups of the segmented binning (0 = by mesh size)
  *   "bin_atomics"             1: global-atomic CSR binning (the path for windows of more than 36,864 tiles)
- *   "bin_capacity"            initial capacity of the (triangle, tile) lists in records (overflow / re-issue tests)
+ *   "bin_capacity"            initial capacity of the (triangle, tile) lists in records (tests of the replay)
+ *   "fan_capacity"            initial capacity of the fan space in triangles (the same)
+ *   "overlap"                 1 (default): geometry + binning of the next draw run on the ctx's second stream beside the
+ *                             tile kernel of the current one; 0: one stream, one kernel after the other
  *   "tile_slot_records"       records per tile slot of the near-first copy (tests of its overflow arena)
  *   "clip_queue"              1: clipped inputs beyond four per 256-triangle block are expanded by a second launch
  *                             (k_geom_clip, one wavefront each over the whole chip) instead of by their block; 0: never;

@@ -45,7 +45,7 @@ pub mod ffi {
         pub frag_covered: u64,
         pub frag_nan: u64,
         pub draws: u32,
-        pub overflow: u32,
+        pub replays: u32,
     }
 
     extern "C" {
@@ -89,7 +89,8 @@ pub const ERR_INVALID: i32 = -1;
 pub const ERR_HIP: i32 = -2;
 pub const ERR_NOMEM: i32 = -3;
 pub const ERR_UNSUPPORTED: i32 = -4;
-/// a device work list overflowed; the ctx has grown it, re-issue the frame
+/// never seen by a caller in practice: a work list that is too small is grown and the draw replayed inside the
+/// library (renderer.rs:269-384 cannot fail); returned only after eight replays in a row were not enough
 pub const ERR_CAPACITY: i32 = -5;
 
 /// vertex-shader table: replaces the `vertex_shader: &F` closure (renderer.rs:105,110)
@@ -192,7 +193,7 @@ impl Renderer {
     pub fn draw(&mut self, mesh: &Mesh, ps: Ps) -> Result<(), Error> {
         self.check(unsafe { ffi::frr_draw(self.ctx, mesh.id, ps as c_int, 0, self.width as i32, 0, self.height as i32) })
     }
-    /// `image_slice.copy_from_slice(frame_buffer.get_data())` (phong.rs:386); on `ERR_CAPACITY` re-issue the frame
+    /// `image_slice.copy_from_slice(frame_buffer.get_data())` (phong.rs:386)
     pub fn read_frame_buffer(&mut self, rgba: &mut [u8], depth: Option<&mut [f32]>) -> Result<(), Error> {
         let n = (self.width as usize) * (self.height as usize);
         assert!(rgba.len() >= n * 4);

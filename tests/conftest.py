@@ -37,3 +37,11 @@ def assert_depth_equal(got, want, err_msg="depth bits differ"):
     gn, wn = np.isnan(got), np.isnan(want)
     np.testing.assert_array_equal(gn, wn, err_msg=err_msg + " (NaN pixels)")
     np.testing.assert_array_equal(got.view(np.uint32)[~gn], want.view(np.uint32)[~wn], err_msg=err_msg)
+
+
+def owned_pixel_rows(H, rank, world, blocked):
+    """bool[H]: the pixel rows rank `rank` of `world` owns (both layouts of frr_set_partition_layout)."""
+    import numpy as np
+    from f_renderer_amd.multigpu import tile_row_owner
+    owner = np.asarray(tile_row_owner((H + 31) // 32, world, blocked))
+    return owner[np.arange(H) // 32] == rank

@@ -15,10 +15,15 @@ def _oracle_depth(oracle, tris, W, H):
     return f
 
 
-def test_bin_capacity_overflow_is_reported_then_recovers(oracle, monkeypatch):
+@pytest.mark.parametrize("path", ["segmented", "atomics"])
+def test_bin_capacity_overflow_is_replayed_inside_the_library(oracle, monkeypatch, path):
+    """Renderer::rasterization cannot fail (renderer.rs:269-384): a (triangle, tile) list that turns out too small is
+    grown and the draw replayed by the library itself; the caller sees a correct frame and `replays` in the statistics."""
     import f_renderer_amd as fr
     from f_renderer_amd import scenes
     monkeypatch.setenv("FRR_BIN_CAP", "2000")            # far too small on purpose
+    if path == "atomics":
+        monkeypatch.setenv("FRR_BIN", "atomics")
     W, H = 256, 192
     tris = scenes.random_clip_triangles(4000, W, H, seed=3, spread=1.0)
     f = _oracle_depth(oracle, tris, W, H)
@@ -26,14 +31,91 @@ def test_bin_capacity_overflow_is_reported_then_recovers(oracle, monkeypatch):
     m = r.upload_mesh(tris, fr.VS_CLIP)
     r.clear()
     r.draw(m, fr.PS_DEPTH)
-    with pytest.raises(fr.FrrError) as e:
-        r.readback()
-    assert e.value.code == fr.FRR_ERR_CAPACITY            # frame flagged invalid, capacity grown
-    r.clear()
-    r.draw(m, fr.PS_DEPTH)                                # re-issue
-    _, d, t = r.readback()
+    _, d, t = r.readback()                                # no error, no re-issue by the caller
     np.testing.assert_array_equal(t, f.tri_id)
     np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
+    st = r.stats()
+    assert st["replays"] >= 1 and st["tris_in"] == 4000 and st["draws"] == 1
+    assert st["tris_setup"] == f.counters.tris_setup and st["frag_covered"] == f.counters.frag_covered
+    r.clear()
+    r.draw(m, fr.PS_DEPTH)                                # the lists have grown: the next frame needs no replay
+    _, d, t = r.readback()
+    np.testing.assert_array_equal(t, f.tri_id)
+    assert r.stats()["replays"] == 0
+
+
+def test_replay_in_the_middle_of_a_frame(oracle, monkeypatch):
+    """Three draws into one frame, the SECOND needs more bin space than there is: the first draw's results stay, the second
+    and third are replayed (the third was cancelled on the device when the second failed) -- ids, depth, colour and the
+    frame statistics are those of a frame that never failed.  Also with caller-bound targets that change between frames."""
+    import torch
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H = 320, 240
+    n = (300, 9000, 700)
+    meshes = []
+    for k, nk in enumerate(n):
+        clip = scenes.random_clip_triangles(nk, W, H, seed=90 + k, spread=1.1, w_jitter=0.4)
+        col = scenes.splitmix_u01(17 + k, nk * 9).reshape(nk, 3, 3).astype(np.float32)
+        meshes.append(np.concatenate([clip, col], axis=2))
+    f = oracle.Frame(W, H)
+    f.clear((9, 8, 7, 6), 0.0)
+    for mk in meshes:
+        f.draw(mk, oracle.VS_CLIP_COLOR, oracle.PS_COLOR, oracle.make_uniforms())
+    if f.counters.frag_nan:
+        pytest.skip("NaN rhw")
+    monkeypatch.setenv("FRR_BIN_CAP", "6000")            # enough for the first and third draw, not for the second
+    r = fr.Renderer(W, H)
+    ms = [r.upload_mesh(mk, fr.VS_CLIP_COLOR) for mk in meshes]
+    sets = [(torch.zeros((H, W), dtype=torch.int32, device="cuda"), torch.zeros((H, W), dtype=torch.float32, device="cuda"),
+             torch.zeros((H, W), dtype=torch.int32, device="cuda")) for _ in range(2)]
+    for frame in range(3):
+        c_, d_, t_ = sets[frame % 2]
+        r.bind_targets(c_.data_ptr(), d_.data_ptr(), t_.data_ptr())
+        r.clear((9, 8, 7, 6), 0.0)
+        for m in ms:
+            r.draw(m, fr.PS_COLOR)
+        r.sync()
+        torch.cuda.synchronize()
+        st = r.stats()
+        assert st["replays"] == (1 if frame == 0 else 0), st
+        assert st["draws"] == 3 and st["tris_in"] == sum(n) and st["tris_setup"] == f.counters.tris_setup
+        assert st["frag_covered"] == f.counters.frag_covered
+        np.testing.assert_array_equal(t_.cpu().numpy().view(np.uint32).ravel(), f.tri_id)
+        np.testing.assert_array_equal(d_.cpu().numpy().view(np.uint32).ravel(), f.depth.view(np.uint32))
+        np.testing.assert_array_equal(c_.cpu().numpy().view(np.uint8).reshape(H, W, 4), f.color)
+    r.close()
+
+
+def test_replay_of_separate_geometry_and_raster_calls(oracle, monkeypatch):
+    """frr_geometry once, frr_raster over two windows (renderer.rs:269-271 allows reusing one geometry): the second window's
+    binning overflows; only that raster pass is replayed, on the intact setup list."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    W, H = 256, 256
+    tris = scenes.random_clip_triangles(5000, W, H, seed=12, spread=1.0)
+    f = oracle.Frame(W, H)
+    f.clear()
+    f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms(), window=(0, W, 0, 64))
+    f2 = oracle.Frame(W, H)
+    f2.clear()
+    f2.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
+    monkeypatch.setenv("FRR_BIN_CAP", "4000")
+    r = fr.Renderer(W, H)
+    m = r.upload_mesh(tris, fr.VS_CLIP)
+    r.clear()
+    r.geometry_processing(m)
+    r.rasterization((0, W), (0, 64), fr.PS_DEPTH)        # a quarter of the frame: fits
+    _, d, t = r.readback()
+    assert r.stats()["replays"] == 0
+    np.testing.assert_array_equal(t, f.tri_id)
+    r.clear()
+    r.geometry_processing(m)
+    r.rasterization((0, W), (0, H), fr.PS_DEPTH)         # the whole frame: does not
+    _, d, t = r.readback()
+    assert r.stats()["replays"] >= 1
+    np.testing.assert_array_equal(t, f2.tri_id)
+    np.testing.assert_array_equal(d.view(np.uint32), f2.depth.view(np.uint32))
 
 
 def test_global_atomic_binning_fallback(oracle, monkeypatch):

@@ -5,6 +5,7 @@ to the single-GPU image and its fragment counts add up; splitting the draw call 
 pixel unchanged (emission indices are frame-global); early-z on/off and repeated runs are identical."""
 import numpy as np
 import pytest
+from .conftest import owned_pixel_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -68,8 +69,7 @@ def test_headline_partition_of_8_stitches_and_counts_add_up(headline, blocked):
         r.draw(r.upload_mesh(headline["tris"], fr.VS_CLIP), fr.PS_DEPTH)
         _, d, t = r.readback()
         covered += r.stats()["frag_covered"]
-        k = -(-((H + 31) // 32) // G)
-        own = np.repeat((rows // k) == rank if blocked else (rows % G) == rank, W)
+        own = np.repeat(owned_pixel_rows(H, rank, G, blocked), W)
         acc_t[own] = t[own]
         acc_d[own] = d[own]
         r.close()
@@ -195,12 +195,11 @@ def test_clip_heavy_textured_scene_partitioned_equals_single_gpu(blocked):
 
     (c0, d0, t0), st0 = render()
     rows = np.arange(Hc) // 32
-    k = -(-((Hc + 31) // 32) // G)
     acc_c, acc_d, acc_t = np.zeros_like(c0), np.zeros_like(d0), np.zeros_like(t0)
     for rank in range(G):
         (c, d, t), st = render(rank)
         assert st["tris_setup"] == st0["tris_setup"]
-        own_rows = (rows // k) == rank if blocked else (rows % G) == rank
+        own_rows = owned_pixel_rows(Hc, rank, G, blocked)
         own = np.repeat(own_rows, Wc)
         acc_d[own] = d[own]
         acc_t[own] = t[own]

@@ -5,7 +5,7 @@ order, so no tolerance is needed or used.
 """
 import numpy as np
 import pytest
-from .conftest import assert_depth_equal
+from .conftest import assert_depth_equal, owned_pixel_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -266,8 +266,7 @@ def test_tile_partition_stitch(oracle, blocked):
         r.draw(r.upload_mesh(tris, fr.VS_CLIP), fr.PS_DEPTH)
         _, d, t = r.readback()
         assert r.stats()["tris_setup"] == full.stats()["tris_setup"]     # the reference's count, on every rank
-        k = -(-((H + 31) // 32) // G)
-        own = np.repeat((rows // k) == rank if blocked else (rows % G) == rank, W)
+        own = np.repeat(owned_pixel_rows(H, rank, G, blocked), W)
         assert (t[~own] == 0xFFFFFFFF).all()
         acc_d[own] = d[own]
         acc_t[own] = t[own]

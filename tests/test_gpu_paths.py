@@ -2,6 +2,7 @@
 every shape of the tile kernel, the fan region's capacity growth."""
 import numpy as np
 import pytest
+from .conftest import assert_depth_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -128,7 +129,7 @@ def test_mixed_geometry_paths_across_draws(oracle):
         np.testing.assert_array_equal(t, f.tri_id)
         np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
         st = r.stats()
-        assert st["tris_setup"] == f.counters.tris_setup and st["overflow"] == 0
+        assert st["tris_setup"] == f.counters.tris_setup and st["replays"] == 0
 
 
 def test_filtered_setup_list_is_not_reused(oracle):
@@ -174,9 +175,9 @@ def test_filtered_setup_list_is_not_reused(oracle):
     np.testing.assert_array_equal(full_d.view(np.uint32), f.depth.view(np.uint32))
 
 
-def test_fan_capacity_overflow_is_reported_then_recovers(oracle):
+def test_fan_capacity_overflow_is_replayed_inside_the_library(oracle):
     """A mesh whose clipped inputs need more fan slots than the first guess (max(one per input + 4096, min(19 per
-    input, 2^20))): the frame is flagged (FRR_ERR_CAPACITY), the capacity grown, the re-issued frame equals the oracle's."""
+    input, 2^20))): the geometry pass fails on the device, the library grows the fan space and replays the draw itself."""
     import f_renderer_amd as fr
     from f_renderer_amd import scenes
     W, H, n = 64, 48, 300000
@@ -192,15 +193,46 @@ def test_fan_capacity_overflow_is_reported_then_recovers(oracle):
     m = r.upload_mesh(tris, fr.VS_CLIP)
     r.clear()
     r.draw(m, fr.PS_DEPTH)
-    with pytest.raises(fr.FrrError) as e:
-        r.sync()
-    assert e.value.code == fr.FRR_ERR_CAPACITY
-    r.clear()
-    r.draw(m, fr.PS_DEPTH)
+    r.sync()                                              # no error: the replay happened in here
     _, d, t = r.readback()
     np.testing.assert_array_equal(t, f.tri_id)
     np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
-    assert r.stats()["tris_setup"] == f.counters.tris_setup
+    st = r.stats()
+    assert st["tris_setup"] == f.counters.tris_setup and st["replays"] >= 1
+
+
+@pytest.mark.parametrize("clip_queue", [0, 1])
+def test_small_fan_space_is_grown_by_replays(oracle, monkeypatch, clip_queue):
+    """Option fan_capacity forces a tiny fan space on a clip-heavy mesh (cheap to run): setup records, ids and depth are the
+    oracle's after the library's own replays, also when frr_geometry is asked for its count and in a second draw of the frame."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    monkeypatch.setenv("FRR_FAN_CAP", "64")
+    monkeypatch.setenv("FRR_CLIP_QUEUE", str(clip_queue))
+    W, H = 200, 150
+    tris = scenes.random_clip_triangles(6000, W, H, seed=8, spread=1.3, w_jitter=0.5)
+    small = scenes.random_clip_triangles(50, W, H, seed=9, spread=0.5)
+    f = oracle.Frame(W, H)
+    f.clear()
+    f.draw(small, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
+    setup = f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms(), keep_setup=True)
+    if f.counters.frag_nan:
+        pytest.skip("NaN rhw")
+    assert setup.shape[0] > 6000 + 64
+    r = fr.Renderer(W, H)
+    m0, m = r.upload_mesh(small, fr.VS_CLIP), r.upload_mesh(tris, fr.VS_CLIP)
+    r.clear()
+    r.draw(m0, fr.PS_DEPTH)
+    n = r.geometry_processing(m, count=True)             # the count is the reference's, replay or not
+    assert n == setup.shape[0]
+    r.rasterization((0, W), (0, H), fr.PS_DEPTH)
+    g = r.setup_triangles()
+    np.testing.assert_array_equal(g["spi"], setup["spi"])
+    _, d, t = r.readback()
+    np.testing.assert_array_equal(t, f.tri_id)
+    assert_depth_equal(d, f.depth)
+    st = r.stats()
+    assert st["replays"] >= 1 and st["tris_setup"] == f.counters.tris_setup and st["draws"] == 2
 
 
 @pytest.mark.parametrize("scene", ["clip_heavy", "phong", "many_rounds"])
@@ -243,7 +275,7 @@ def test_draw_of_clipped_textured_and_many_round_meshes(oracle, scene):
     if scene == "phong":
         np.testing.assert_array_equal(c, f.color)
     st = r.stats()
-    assert st["tris_setup"] == f.counters.tris_setup and st["overflow"] == 0
+    assert st["tris_setup"] == f.counters.tris_setup and st["replays"] == 0
     if scene != "many_rounds":
         g = r.setup_triangles()
         assert g.shape[0] == setup.shape[0]

@@ -3,6 +3,7 @@ one-pixel frames), clip-heavy and negative-w triangle soups, two draws per frame
 2- or 3-rank partition (both layouts; dense-owned geometry) stitched back together."""
 import numpy as np
 import pytest
+from .conftest import owned_pixel_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -47,14 +48,13 @@ def test_random_frame_and_partition(oracle, W, H, n, spread, wj, seed):
     assert st["frag_covered"] == f.counters.frag_covered and st["tris_setup"] == f.counters.tris_setup
     G = 2 + seed % 2
     rows = np.arange(H) // 32
-    k = -(-((H + 31) // 32) // G)
     for blocked in (False, True):
         acc_t = np.full_like(t, 0xFFFFFFFF)
         acc_d = np.zeros_like(d)
         cov = 0
         for rank in range(G):
             _, dr, tr, sr = render((rank, G), blocked)
-            own = np.repeat((rows // k) == rank if blocked else (rows % G) == rank, W)
+            own = np.repeat(owned_pixel_rows(H, rank, G, blocked), W)
             acc_t[own] = tr[own]
             acc_d[own] = dr[own]
             cov += sr["frag_covered"]

@@ -1,0 +1,31 @@
+"""Dev tool: host enqueue cost and frame time of the headline frame with the second stream on and off (option overlap)."""
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch  # noqa
+import f_renderer_amd as fr
+from f_renderer_amd import scenes
+
+cfg = scenes.build_config(os.environ.get("CFG", "headline"))
+W, H = cfg["W"], cfg["H"]
+N = int(os.environ.get("N", "200"))
+for overlap in ([int(os.environ["OVERLAP"])] if os.environ.get("OVERLAP") else [0, 1, 0, 1]):
+    r = fr.Renderer(W, H)
+    r.set_option("overlap", overlap)
+    if cfg["tex"] is not None:
+        r.set_texture(0, cfg["tex"])
+        eye, at, up, fovy, aspect, zn, zf = scenes.demo_camera(W, H)
+        r.set_uniforms(view=fr.set_look_at(eye, at, up), proj=fr.set_perspective(fovy, aspect, zn, zf), view_pos=eye, texture_slot=0)
+    r.set_count_fragments(False)
+    m = r.upload_mesh(cfg["mesh"], getattr(fr, "VS_" + cfg["vs"]))
+    ps = getattr(fr, "PS_" + cfg["ps"])
+    for _ in range(10):
+        r.clear(); r.draw(m, ps)
+    r.sync()
+    t0 = time.perf_counter()
+    for _ in range(N):
+        r.clear(); r.draw(m, ps)
+    t1 = time.perf_counter()
+    r.sync()
+    t2 = time.perf_counter()
+    print(f"overlap={overlap}: host enqueue {(t1 - t0) / N * 1e6:.1f} us/frame, frame {(t2 - t0) / N * 1e6:.1f} us, replays {r.stats()['replays']}", flush=True)
+    r.close()
