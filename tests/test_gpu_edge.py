@@ -61,7 +61,7 @@ def test_replay_in_the_middle_of_a_frame(oracle, monkeypatch):
     f = oracle.Frame(W, H)
     f.clear((9, 8, 7, 6), 0.0)
     for mk in meshes:
-        f.draw(mk, oracle.VS_CLIP_COLOR, oracle.PS_COLOR, oracle.make_uniforms())
+        f.draw(mk, oracle.VS_CLIP_COLOR, oracle.PS_COLOR, oracle.make_uniforms(), tri_id_base=int(f.counters.tris_setup))
     if f.counters.frag_nan:
         pytest.skip("NaN rhw")
     monkeypatch.setenv("FRR_BIN_CAP", "6000")            # enough for the first and third draw, not for the second

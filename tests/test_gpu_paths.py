@@ -215,7 +215,7 @@ def test_small_fan_space_is_grown_by_replays(oracle, monkeypatch, clip_queue):
     f = oracle.Frame(W, H)
     f.clear()
     f.draw(small, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms())
-    setup = f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms(), keep_setup=True)
+    setup = f.draw(tris, oracle.VS_CLIP, oracle.PS_DEPTH, oracle.make_uniforms(), keep_setup=True, tri_id_base=int(f.counters.tris_setup))
     if f.counters.frag_nan:
         pytest.skip("NaN rhw")
     assert setup.shape[0] > 6000 + 64
