@@ -220,7 +220,8 @@ class Run:
             mk = lambda dt, fill: [torch.full((HP, W), fill, dtype=dt, device="cuda") for _ in range(self.nsets)]  # noqa: E731
             self.color, self.depth, self.tri_id = mk(torch.int32, 0), mk(torch.float32, 0.0), mk(torch.int32, -1)
             self.r = self.make_renderer(local_rank)
-            self.r.bind_targets(self.color[0].data_ptr(), self.depth[0].data_ptr(), self.tri_id[0].data_ptr())
+            if dist is not None:   # (N = 1: the library's own targets -- two sets, so that two frames are in flight)
+                self.r.bind_targets(self.color[0].data_ptr(), self.depth[0].data_ptr(), self.tri_id[0].data_ptr())
             self.r.set_partition(rank, world, blocked=True)   # contiguous slabs: the gather needs no staging copies
             self.dev_in = torch.from_numpy(cfg["mesh"]).to("cuda")  # resident in HBM before timing
             self.mesh = self.r.bind_mesh_device(self.dev_in.data_ptr(), self.ntris, self.vs, keepalive=self.dev_in)
@@ -334,6 +335,20 @@ class Run:
             r.profile_enable(False)
             stats = r.stats()
 
+            # N = 1: the image the LAST timed frame left in the targets against the committed digests of the oracle's
+            # frame (tests/golden/frames.json: data only, nothing of oracle/ runs here)
+            self._golden_match = None
+            gold = golden_counts(self.cfg_name)
+            if self.world == 1 and gold:
+                sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+                if self.gathers is None:
+                    c_, d_, t_ = r.readback()
+                else:
+                    r.sync()
+                    s_last, H = (self.frame_no - 1) % self.nsets, self.H
+                    c_, d_, t_ = (x[s_last][:H].contiguous().cpu().numpy() for x in (self.color, self.depth, self.tri_id))
+                self._golden_match = bool(sha(d_) == gold["sha256_depth"] and sha(t_) == gold["sha256_tri_id"] and sha(c_) == gold["sha256_rgba8"])
+
             # multi-GPU image check on rank 0: the gathered image of the LAST timed frame == the unpartitioned render,
             # byte for byte; triangle ids through one extra (untimed) frame's gather
             image_equal = None
@@ -378,6 +393,8 @@ class Run:
                        "shader": f"VS_{self.cfg['vs']}/PS_{self.cfg['ps']}", "varyings": self.K, "tile": "32x32",
                        "partition": f"tile rows in {world} contiguous block(s)" + (f", RCCL gather of {gathered} to rank 0" if self.gathers is not None else "")},
         }
+        if self._golden_match is not None:
+            out["image_matches_golden"] = self._golden_match
         if image_equal is not None:
             out["gathered_image_equal"] = image_equal
             out["render_us_max"] = round(float(t[1].item()), 2)

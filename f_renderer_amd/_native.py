@@ -20,6 +20,8 @@ HIPCC_FLAGS = [
     # bit-exactness contract with the reference's Rust fp32 semantics: no FMA contraction,
     # no fast-math; IEEE div/sqrt and preserved denormals are hipcc defaults and stay on.
     "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+    # user shaders (frr_shader_register): the device headers' text is embedded (.incbin) and compiled at run time by hiprtc
+    "-DFRR_CSRC_DIR=\"%s\"" % os.path.join(_HERE, "csrc"), "-L/opt/rocm/lib", "-lhiprtc", "-Wl,-rpath,/opt/rocm/lib",
 ]
 
 FRR_OK, FRR_ERR_INVALID, FRR_ERR_HIP, FRR_ERR_NOMEM, FRR_ERR_UNSUPPORTED, FRR_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
@@ -102,6 +104,7 @@ SIGNATURES = {
     "frr_set_partition_layout": (C.c_int, [C.c_void_p, C.c_int]),
     "frr_owned_band_count": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "frr_owned_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
+    "frr_partition_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
     "frr_set_count_fragments": (C.c_int, [C.c_void_p, C.c_int]),
     "frr_bind_targets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frr_target_ptrs": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_void_p)]),
@@ -110,6 +113,8 @@ SIGNATURES = {
     "frr_mesh_free": (C.c_int, [C.c_void_p, C.c_int]),
     "frr_texture_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32]),
     "frr_set_uniforms": (C.c_int, [C.c_void_p, _P(Uniforms)]),
+    "frr_shader_register": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, _P(C.c_int)]),
+    "frr_set_user_uniforms": (C.c_int, [C.c_void_p, _P(C.c_float), C.c_int]),
     "frr_vs_input_floats": (C.c_int, [C.c_int]),
     "frr_vs_num_varyings": (C.c_int, [C.c_int]),
     "frr_clear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float]),

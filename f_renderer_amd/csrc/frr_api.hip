@@ -7,8 +7,27 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <hip/hiprtc.h>
+
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
+
+// The text of the device headers, for frr_shader_register (hiprtc compiles user shaders into the library's own kernels):
+// the assembler copies the files into .rodata of the host object.
+#ifndef FRR_CSRC_DIR
+#define FRR_CSRC_DIR "f_renderer_amd/csrc"   // (builds started at the repository root; f_renderer_amd/_native.py passes the absolute path)
+#endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define FRR_EMBED(sym, file) __asm__(".pushsection .rodata\n.global " #sym "\n" #sym ":\n.incbin \"" FRR_CSRC_DIR "/" file "\"\n.byte 0\n.popsection\n")
+FRR_EMBED(frr_src_device_h, "frr_device.h");
+FRR_EMBED(frr_src_exact_h, "frr_exact.h");
+FRR_EMBED(frr_src_kernels_h, "frr_kernels.h");
+FRR_EMBED(frr_src_raster_h, "frr_raster.h");
+FRR_EMBED(frr_src_frr_h, "../../include/frr.h");
+#endif
+extern "C" const char frr_src_device_h[], frr_src_exact_h[], frr_src_kernels_h[], frr_src_raster_h[], frr_src_frr_h[];
 
 using namespace frr;
 
@@ -32,6 +51,26 @@ struct Texture {
 };
 struct ProfRec { int kid; hipEvent_t a, b; };
 
+// ---- user shaders (frr_shader_register): a per-process registry of code objects, loaded per ctx on first use ---------
+constexpr int kSpanShapes[6][2] = {{16, 4}, {8, 6}, {6, 6}, {4, 8}, {4, 6}, {LIGHT_NW, 6}};   // the shapes launch_raster knows
+struct UserShader {
+    int nf = 0, K = 0;
+    std::vector<char> code;
+    std::string geom, clip, span[2][6];   // lowered kernel names ([count fragments][shape])
+};
+std::mutex g_shader_mu;
+std::vector<UserShader *> g_shaders;      // id = FRR_SHADER_USER_BASE + index; never shrinks
+const UserShader *user_shader(int id)
+{
+    std::lock_guard<std::mutex> lk(g_shader_mu);
+    const int i = id - FRR_SHADER_USER_BASE;
+    return (i >= 0 && i < (int)g_shaders.size()) ? g_shaders[(size_t)i] : nullptr;
+}
+struct UserModule {
+    hipModule_t mod = nullptr;
+    hipFunction_t geom = nullptr, clip = nullptr, span[2][6] = {};
+};
+
 // Workspace of one geometry pass / one raster pass.  There are two of each, used alternately (parity of the pass), so
 // that the geometry + binning kernels of pass n + 1 can run on the ctx's second stream while the tile kernel of pass n
 // still reads what pass n left (frr_device.h: GeomTab / BinTab are the device-side halves of the same scheme).
@@ -46,13 +85,13 @@ struct GeomSet {
     uint4 *pbox = nullptr; size_t pbox_cap = 0;
     uint32_t *bcount = nullptr; size_t bcount_cap = 0;          // [geometry blocks] dense binning entries per block (GeomArgs::bcount)
     uint2 *clipq = nullptr; size_t clipq_cap = 0;               // [input triangles] the clip kernel's queue (GeomArgs::clipq)
-    uint64_t last_reader = 0;                                   // serial of the latest tile kernel that reads this set
+    hipEvent_t reader_ev = nullptr; bool reader_pending = false; // fires when the latest tile kernel that reads this set is done
 };
 struct BinSet {
     uint4 *bins = nullptr; size_t bin_cap = 0;   // 16-byte cull records, one per (triangle, tile) pair
     uint4 *bins2 = nullptr; size_t bin2_cap = 0; // the same in near-first order per tile (tile kernel pre-pass)
     uint32_t *bin_matrix = nullptr; size_t bin_matrix_cap = 0; // [G][ntiles] per-chunk tile histograms
-    uint64_t last_reader = 0;
+    hipEvent_t reader_ev = nullptr; bool reader_pending = false;
 };
 
 struct GeomFilter { bool active; int32_t y0, y1; int rank, world; bool blocked; };
@@ -61,6 +100,7 @@ struct GeomFilter { bool active; int32_t y0, y1; int rank, world; bool blocked; 
 // the commands from a failed one onwards can be replayed (finish()).
 struct FrameState {
     uint8_t *color = nullptr; float *depth = nullptr; uint32_t *tri_id = nullptr; // the frame targets (own or caller-bound)
+    int tset = 0;                                                                 // which of the ctx's own target sets is current
     int rank = 0, world = 1; bool part_blocked = false;                           // tile-row ownership (frr_set_partition*)
     // frr_clear is deferred: the first full-window draw of the span kernel performs it inside the tile kernel
     // (keys start from the clear depth, every pixel of the tile is written); anything else that looks at the
@@ -102,15 +142,24 @@ struct frr_ctx {
     hipStream_t gstream = nullptr;  // private: geometry + binning of the next pass, beside the tile kernel of the current one
     bool own_stream = false;
     bool overlap = true;            // option overlap: use gstream (else everything runs on `stream`)
-    uint8_t *own_color = nullptr; float *own_depth = nullptr; uint32_t *own_tri_id = nullptr;
+    // The ctx's own frame targets: TWO sets.  A frame that starts with frr_clear on own targets takes the other set and
+    // its tile kernels the other tile stream (tstream2 for set 1), so that the tile kernel of frame n + 1 fills the drain
+    // of frame n's (2,040 tiles on 1,536 workgroup slots end with a third of the chip idle).  Nobody can look at own targets
+    // except through this library (frr_readback, frr_target_ptrs, which join the streams first), so the only visible
+    // change is that frr_target_ptrs' pointers are those of the CURRENT frame.  Caller-bound targets: one set, one stream.
+    uint8_t *own_color[2] = {}; float *own_depth[2] = {}; uint32_t *own_tri_id[2] = {};
+    hipStream_t tstream2 = nullptr;  // tile kernels / clears of own target set 1
+    hipEvent_t ev_t2 = nullptr;      // joins tstream2 into `stream`
+    bool t2_dirty = false;           // tstream2 holds work `stream` has not waited for
+    int frames_in_flight = 2;        // option frames_in_flight (1: one set, one tile stream)
     Counters *cnt = nullptr;
     FrameState fs;
     GeomSet gset[2];
     BinSet bset[2];
-    // cross-stream ordering: tile kernels are numbered; ev_tile[n & 3] fires when tile kernel n is done (the second
+    // cross-stream ordering: every workspace set has an event that fires when the latest tile kernel reading it is done (the second
     // stream waits for it before it overwrites a workspace that kernel reads), ev_bin[k & 3] when binning k is done
-    hipEvent_t ev_tile[4] = {}, ev_bin[4] = {}, ev_join = nullptr;
-    uint64_t tile_serial = 0, g_waited = 0, bin_serial = 0;
+    hipEvent_t ev_bin[4] = {}, ev_join = nullptr;
+    uint64_t bin_serial = 0;
     bool need_join = true;          // the second stream has not yet waited for what the caller put on `stream` (mesh data)
     // command log since the last synchronisation point / frr_clear (finish(): replay)
     std::vector<Cmd> log;
@@ -132,6 +181,7 @@ struct frr_ctx {
     uint32_t max_tiles = 0;
     bool lds_attr_set = false;
     std::vector<Mesh> meshes;
+    std::map<int, UserModule> user_modules;   // user shader id -> its code object loaded on this ctx's device
     Texture tex[FRR_MAX_TEXTURES];
     frr_uniforms uni;
     DevUniforms duni;
@@ -169,12 +219,30 @@ int fail(frr_ctx *c, int code, const std::string &msg)
     } while (0)
 
 hipStream_t gstream_of(const frr_ctx *c) { return c->overlap ? c->gstream : c->stream; }
+// the stream of everything that touches the current frame targets
+bool own_targets(const frr_ctx *c)
+{
+    const FrameState &f = c->fs;
+    return f.color == c->own_color[f.tset] && f.depth == c->own_depth[f.tset] && f.tri_id == c->own_tri_id[f.tset];
+}
+hipStream_t tstream_of(const frr_ctx *c) { return (c->tstream2 && c->fs.tset == 1 && own_targets(c)) ? c->tstream2 : c->stream; }
 
-// both streams idle
+// all streams idle
 int drain(frr_ctx *c)
 {
     if (c->gstream) HIP_TRY(c, hipStreamSynchronize(c->gstream));
+    if (c->tstream2) HIP_TRY(c, hipStreamSynchronize(c->tstream2));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->t2_dirty = false;
+    return FRR_OK;
+}
+// the caller's stream waits for the second tile stream: what the caller enqueues next sees every frame issued so far
+int join_tile_streams(frr_ctx *c)
+{
+    if (!c->t2_dirty) return FRR_OK;
+    HIP_TRY(c, hipEventRecord(c->ev_t2, c->tstream2));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_t2, 0));
+    c->t2_dirty = false;
     return FRR_OK;
 }
 
@@ -191,14 +259,13 @@ template <typename T> int ensure(frr_ctx *c, T *&p, size_t &cap, size_t need)
 }
 
 // ---- cross-stream ordering (no-ops when everything runs on one stream) ----------------------------------------------
-// the second stream waits until tile kernel `serial` (and every earlier one) is done
-int gstream_wait_tile(frr_ctx *c, uint64_t serial)
+// the second stream waits until the latest tile kernel that reads a workspace set is done
+template <class SET> int gstream_wait_readers(frr_ctx *c, SET &S)
 {
-    if (!c->overlap || serial <= c->g_waited) return FRR_OK;
-    // (the ring holds the latest four; an older kernel is covered by waiting for the oldest one still in the ring)
-    const uint64_t s = std::max<uint64_t>(serial, c->tile_serial >= 3 ? c->tile_serial - 3 : 0);
-    HIP_TRY(c, hipStreamWaitEvent(c->gstream, c->ev_tile[s & 3], 0));
-    c->g_waited = s;
+    if (!S.reader_pending) return FRR_OK;
+    S.reader_pending = false;
+    if (gstream_of(c) == c->stream && !c->tstream2) return FRR_OK;   // one stream: already in order
+    HIP_TRY(c, hipStreamWaitEvent(gstream_of(c), S.reader_ev, 0));
     return FRR_OK;
 }
 // the second stream waits for everything the caller's stream holds so far (mesh data written by the caller)
@@ -208,25 +275,25 @@ int gstream_join(frr_ctx *c)
     HIP_TRY(c, hipEventRecord(c->ev_join, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(c->gstream, c->ev_join, 0));
     c->need_join = false;
-    c->g_waited = c->tile_serial;
     return FRR_OK;
 }
-// the caller's stream waits for what the second stream holds so far (binning -> tile kernel)
-int stream_wait_gstream(frr_ctx *c)
+// the tile stream waits for what the second stream holds so far (binning -> tile kernel)
+int tstream_wait_gstream(frr_ctx *c)
 {
-    if (!c->overlap) return FRR_OK;
+    if (gstream_of(c) == tstream_of(c)) return FRR_OK;
     hipEvent_t e = c->ev_bin[++c->bin_serial & 3];
-    HIP_TRY(c, hipEventRecord(e, c->gstream));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, e, 0));
+    HIP_TRY(c, hipEventRecord(e, gstream_of(c)));
+    HIP_TRY(c, hipStreamWaitEvent(tstream_of(c), e, 0));
     return FRR_OK;
 }
-// a tile kernel has just been launched: number it
-int tile_launched(frr_ctx *c, GeomSet &gs, BinSet *bs)
+// a tile kernel has just been launched: the workspace sets it reads are busy until it is done
+int tile_launched(frr_ctx *c, GeomSet &gs, BinSet &bs)
 {
-    ++c->tile_serial;
-    gs.last_reader = c->tile_serial;
-    if (bs) bs->last_reader = c->tile_serial;
-    if (c->overlap) HIP_TRY(c, hipEventRecord(c->ev_tile[c->tile_serial & 3], c->stream));
+    hipStream_t ts = tstream_of(c);
+    if (ts == c->tstream2) c->t2_dirty = true;
+    if (gstream_of(c) == c->stream && !c->tstream2) return FRR_OK;   // one stream
+    HIP_TRY(c, hipEventRecord(gs.reader_ev, ts)); gs.reader_pending = true;
+    HIP_TRY(c, hipEventRecord(bs.reader_ev, ts)); bs.reader_pending = true;
     return FRR_OK;
 }
 
@@ -305,6 +372,23 @@ void blocked_rows(int tiles_y, int rank, int world, int *t0, int *t1)
     *t1 = *t0 + q + (rank < r ? 1 : 0);
 }
 
+// the code object of user shader `id` on this ctx's device
+int user_module(frr_ctx *c, int id, const UserModule **out)
+{
+    auto it = c->user_modules.find(id);
+    if (it != c->user_modules.end()) { *out = &it->second; return FRR_OK; }
+    const UserShader *us = user_shader(id);
+    if (!us) return fail(c, FRR_ERR_INVALID, "unknown shader id");
+    UserModule m;
+    HIP_TRY(c, hipModuleLoadData(&m.mod, us->code.data()));
+    HIP_TRY(c, hipModuleGetFunction(&m.geom, m.mod, us->geom.c_str()));
+    HIP_TRY(c, hipModuleGetFunction(&m.clip, m.mod, us->clip.c_str()));
+    for (int cnt = 0; cnt < 2; ++cnt)
+        for (int sh = 0; sh < 6; ++sh) HIP_TRY(c, hipModuleGetFunction(&m.span[cnt][sh], m.mod, us->span[cnt][sh].c_str()));
+    *out = &(c->user_modules[id] = m);
+    return FRR_OK;
+}
+
 constexpr uint32_t kClipGrid = 2048;      // workgroups of k_geom_clip (four wavefronts each, one triangle per wavefront and step)
 
 template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks, const DevUniforms &du)
@@ -316,8 +400,17 @@ template <int VS> void launch_geometry(frr_ctx *c, GeomArgs &g, uint32_t nblocks
 }
 
 // the geometry kernel for the VS of the mesh
-void launch_geometry_vs(frr_ctx *c, GeomArgs &g, uint32_t nblocks, int vs, const DevUniforms &du)
+void launch_geometry_vs(frr_ctx *c, GeomArgs &g, uint32_t nblocks, int vs, const DevUniforms &du, const UserModule *um)
 {
+    if (um) {   // a user shader: the same kernels, compiled with the user's functions (frr_shader_register)
+        hipStream_t st = gstream_of(c);
+        ProfScope p(c, KID_GEOM, st);
+        DevUniforms d = du;
+        void *args[] = {&g, &d};
+        (void)hipModuleLaunchKernel(um->geom, nblocks, 1, 1, GEOM_BLOCK, 1, 1, 0, st, args, nullptr);
+        if (g.use_clipq) (void)hipModuleLaunchKernel(um->clip, std::min<uint32_t>(kClipGrid, nblocks * 4u), 1, 1, GEOM_BLOCK, 1, 1, 0, st, args, nullptr);
+        return;
+    }
     switch (vs) {
     case FRR_VS_CLIP: launch_geometry<FRR_VS_CLIP>(c, g, nblocks, du); break;
     case FRR_VS_CLIP_COLOR: launch_geometry<FRR_VS_CLIP_COLOR>(c, g, nblocks, du); break;
@@ -358,16 +451,17 @@ SpanShape span_shape(const frr_ctx *c, uint32_t grid, uint64_t ntris, int ps_id)
 
 template <int K, int PS> void launch_raster(frr_ctx *c, const RasterArgs &a, uint32_t grid, const SpanShape sh, const DevUniforms &du, bool count_frags)
 {
-    ProfScope p(c, KID_RASTER, c->stream);
+    hipStream_t ts = tstream_of(c);
+    ProfScope p(c, KID_RASTER, ts);
     if (c->raster_sweep) {
-        hipLaunchKernelGGL((k_raster<K, PS>), dim3(grid), dim3(256), 0, c->stream, a, du);
+        hipLaunchKernelGGL((k_raster<K, PS>), dim3(grid), dim3(256), 0, ts, a, du);
     } else {
         // the span algebra needs every coordinate it touches within +-SPAN_SAFE (no i32 wrap)
         const int win_safe = a.x0 >= -SPAN_SAFE && a.y0 >= -SPAN_SAFE && a.x1 <= SPAN_SAFE && a.y1 <= SPAN_SAFE;
         auto go = [&](auto count_tag, auto nw_tag, auto occ_tag) {
             constexpr bool CNT = decltype(count_tag)::value;
             constexpr int NWV = decltype(nw_tag)::value, OCCV = decltype(occ_tag)::value;
-            hipLaunchKernelGGL((k_raster_span<K, PS, CNT, NWV, OCCV>), dim3(grid), dim3(NWV * 64), 0, c->stream, a, du, win_safe);
+            hipLaunchKernelGGL((k_raster_span<K, PS, CNT, NWV, OCCV>), dim3(grid), dim3(NWV * 64), 0, ts, a, du, win_safe);
         };
         auto go_nw = [&](auto count_tag) {
             if (sh.nw == LIGHT_NW) go(count_tag, std::integral_constant<int, LIGHT_NW>{}, std::integral_constant<int, 6>{});
@@ -386,13 +480,15 @@ int clear_now(frr_ctx *c, uint32_t packed, float depth)
 {
     const FrameState &f = c->fs;
     const uint32_t n = c->W * c->H, n4 = n / 4;
+    hipStream_t ts = tstream_of(c);
+    if (ts == c->tstream2) c->t2_dirty = true;
     {
-        ProfScope p(c, KID_CLEAR, c->stream);
+        ProfScope p(c, KID_CLEAR, ts);
         uint32_t grid = std::min<uint32_t>((n4 + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_clear, dim3(grid ? grid : 1), dim3(256), 0, c->stream, (uint4 *)f.color, (uint4 *)f.depth,
+        hipLaunchKernelGGL(k_clear, dim3(grid ? grid : 1), dim3(256), 0, ts, (uint4 *)f.color, (uint4 *)f.depth,
                            (uint4 *)f.tri_id, n4, packed, depth);
         if (n4 * 4 < n)
-            hipLaunchKernelGGL(k_clear_tail, dim3(1), dim3(64), 0, c->stream, (uint32_t *)f.color, (uint32_t *)f.depth,
+            hipLaunchKernelGGL(k_clear_tail, dim3(1), dim3(64), 0, ts, (uint32_t *)f.color, (uint32_t *)f.depth,
                                f.tri_id, n4 * 4, n, packed, depth);
     }
     HIP_TRY(c, hipGetLastError());
@@ -410,7 +506,8 @@ int settle_targets(frr_ctx *c)
     } else if (f.unowned_debt) {
         RowOwner own = {f.rank, f.world, f.part_blocked ? 1 : 0, 0, 0};
         if (own.blocked) blocked_rows(f.debt_tiles_y, f.rank, f.world, &own.brow0, &own.brow1);
-        hipLaunchKernelGGL(k_clear_unowned_rows, dim3(c->H), dim3(256), 0, c->stream, (uint32_t *)f.color, (uint32_t *)f.depth,
+        if (tstream_of(c) == c->tstream2) c->t2_dirty = true;
+        hipLaunchKernelGGL(k_clear_unowned_rows, dim3(c->H), dim3(256), 0, tstream_of(c), (uint32_t *)f.color, (uint32_t *)f.depth,
                            f.tri_id, c->W, c->H, own, f.clear_rgba, f.clear_depth);
         HIP_TRY(c, hipGetLastError());
         f.unowned_debt = false;
@@ -437,6 +534,8 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
     const int par = f.gpar ^ 1;
     GeomSet &S = c->gset[par];
     int rc;
+    const UserModule *um = nullptr;
+    if (m.vs >= FRR_SHADER_USER_BASE && (rc = user_module(c, m.vs, &um)) != FRR_OK) return rc;
     // fan space: clipped inputs are the ones that straddle a frustum plane, usually few; room for as many fan triangles
     // as there are inputs (+ 4096) to start with, grown on demand (the pass then fails on the device and finish() replays
     // it with more) up to the worst case of 19 per input (small meshes get their worst case outright: 2^20 slots are cheap) ...
@@ -459,14 +558,14 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
     if ((rc = ensure(c, S.recs, S.setup_cap, std::max<size_t>(slots, 1024))) != FRR_OK) return rc;
     if ((rc = ensure(c, S.pbox, S.pbox_cap, S.setup_cap)) != FRR_OK) return rc;
     if ((rc = ensure(c, S.bcount, S.bcount_cap, (size_t)nblocks + 1)) != FRR_OK) return rc;
-    if (K > 0 && (rc = ensure(c, S.vary, S.vary_cap, (size_t)S.setup_cap * 3 * 8 /* K <= 8 in the shader table */)) != FRR_OK) return rc;
+    if (K > 0 && (rc = ensure(c, S.vary, S.vary_cap, (size_t)S.setup_cap * 3 * std::max(K, 8) /* (K <= 8 in the shader table) */)) != FRR_OK) return rc;
     const bool use_clipq = nt > 0 && (c->clip_queue > 0 || (c->clip_queue < 0 && c->clip_queue_auto));
     if (use_clipq && (rc = ensure(c, S.clipq, S.clipq_cap, (size_t)nt)) != FRR_OK) return rc;
     if ((rc = scan_now(c)) != FRR_OK) return rc;   // the previous pass's n_emit feeds this pass's tri_base
     // second stream: after whatever the caller's stream holds that this pass may read (first use), and after the tile
     // kernel that last read this workspace
     if ((rc = gstream_join(c)) != FRR_OK) return rc;
-    if ((rc = gstream_wait_tile(c, S.last_reader)) != FRR_OK) return rc;
+    if ((rc = gstream_wait_readers(c, S)) != FRR_OK) return rc;
     GeomArgs g;
     g.in = m.dev; g.ntris = (uint32_t)nt; g.width = c->W; g.height = c->H;
     g.fan_cap = (uint32_t)fan_cap;
@@ -494,7 +593,7 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
     if (nt == 0) {
         hipLaunchKernelGGL(k_geom_empty, dim3(1), dim3(64), 0, gstream_of(c), g);
     } else {
-        launch_geometry_vs(c, g, nblocks, m.vs, cmd.duni);
+        launch_geometry_vs(c, g, nblocks, m.vs, cmd.duni, um);
         f.scan_pending = true;
     }
     HIP_TRY(c, hipGetLastError());
@@ -508,6 +607,8 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
     const int32_t x0 = cmd.x0, x1 = cmd.x1, y0 = cmd.y0, y1 = cmd.y1;
     const int ps_id = cmd.ps;
     const int64_t ww = (int64_t)x1 - x0, wh = (int64_t)y1 - y0;
+    const UserModule *um = nullptr;
+    if (ps_id >= FRR_SHADER_USER_BASE) { const int rcu = user_module(c, ps_id, &um); if (rcu != FRR_OK) return rcu; }
     bool fuse = false;
     if (f.clear_pending) {
         const bool full = x0 == 0 && y0 == 0 && x1 == (int32_t)c->W && y1 == (int32_t)c->H;
@@ -533,7 +634,7 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
     if (!c->dbg_tiles && getenv("FRR_DEBUG_TILES")) {
         if (hipMalloc((void **)&c->dbg_tiles, (size_t)c->max_tiles * 64) != hipSuccess) c->dbg_tiles = nullptr;
     }
-    if (c->dbg_tiles) (void)hipMemsetAsync(c->dbg_tiles, 0, (size_t)c->max_tiles * 64, c->stream);
+    if (c->dbg_tiles) (void)hipMemsetAsync(c->dbg_tiles, 0, (size_t)c->max_tiles * 64, tstream_of(c));
     a.dbg_tiles = c->dbg_tiles;
 #endif
     a.seg = nullptr; a.nseg = 0;
@@ -585,7 +686,7 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
         a.bin_cap = (uint32_t)std::min<size_t>(B.bin_cap, 0xBFFFFFFFu);
         if ((rc = ensure(c, B.bins2, B.bin2_cap, (size_t)ltiles * SL + a.bin_cap)) != FRR_OK) return rc;
         a.bins2 = B.bins2;
-        if ((rc = gstream_wait_tile(c, B.last_reader)) != FRR_OK) return rc;   // the tile kernel that last read this workspace
+        if ((rc = gstream_wait_readers(c, B)) != FRR_OK) return rc;   // the tile kernel that last read this workspace
         {
             ProfScope p(c, KID_BIN_SEG, gs);
             hipLaunchKernelGGL(k_bin_seg, dim3(G + do_scan), dim3(BIN_WG), lds, gs, a, ltiles, B.bin_matrix, stage_cap,
@@ -596,7 +697,8 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
     } else {
         // fallback for frames with more tiles than fit LDS counters: global atomics (one set of tile tables: after every
         // tile kernel so far)
-        if ((rc = gstream_wait_tile(c, c->tile_serial)) != FRR_OK) return rc;
+        for (GeomSet &G2 : c->gset) if ((rc = gstream_wait_readers(c, G2)) != FRR_OK) return rc;
+        for (BinSet &B2 : c->bset) if ((rc = gstream_wait_readers(c, B2)) != FRR_OK) return rc;
         if ((rc = scan_now(c)) != FRR_OK) return rc;
         const uint32_t bin_grid = (uint32_t)std::min<uint64_t>((f.geom_ntris + f.geom_fan_cap + 255) / 256, 2048);
         { ProfScope p(c, KID_BIN_COUNT, gs); hipLaunchKernelGGL(k_bin<false>, dim3(bin_grid), dim3(256), 0, gs, a, f.geom_fan_cap); }
@@ -605,8 +707,17 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
     }
     cmd.par = q;
     HIP_TRY(c, hipGetLastError());
-    if ((rc = stream_wait_gstream(c)) != FRR_OK) return rc;   // the tile kernel runs on the caller's stream, after the binning
-    if (grid) {
+    if ((rc = tstream_wait_gstream(c)) != FRR_OK) return rc;   // the tile kernel runs on the targets' stream, after the binning
+    if (grid && um) {
+        hipStream_t ts = tstream_of(c);
+        ProfScope p(c, KID_RASTER, ts);
+        int shi = 4;
+        for (int k = 0; k < 6; ++k) if (kSpanShapes[k][0] == sh.nw && kSpanShapes[k][1] == sh.occ) shi = k;
+        const int win_safe = a.x0 >= -SPAN_SAFE && a.y0 >= -SPAN_SAFE && a.x1 <= SPAN_SAFE && a.y1 <= SPAN_SAFE;
+        RasterArgs ra = a; DevUniforms d = cmd.duni; int ws = win_safe;
+        void *args[] = {&ra, &d, &ws};
+        (void)hipModuleLaunchKernel(um->span[cmd.count_frags ? 1 : 0][shi], grid, 1, 1, (unsigned)kSpanShapes[shi][0] * 64u, 1, 1, 0, ts, args, nullptr);
+    } else if (grid) {
         switch (ps_id) {
         case FRR_PS_DEPTH: launch_raster<0, FRR_PS_DEPTH>(c, a, grid, sh, cmd.duni, cmd.count_frags); break;
         case FRR_PS_FLAT: launch_raster<0, FRR_PS_FLAT>(c, a, grid, sh, cmd.duni, cmd.count_frags); break;
@@ -616,12 +727,12 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
         }
     }
     HIP_TRY(c, hipGetLastError());
-    if ((rc = tile_launched(c, S, &B)) != FRR_OK) return rc;
+    if ((rc = tile_launched(c, S, B)) != FRR_OK) return rc;
     if (fuse) {
         f.clear_pending = false;
         // the tile rows of other ranks missed this clear: owed to the ctx's own targets (frr_readback shows the
         // whole image); caller-bound targets of a partitioned ctx only ever have their owned rows defined
-        f.unowned_debt = f.world > 1 && f.color == c->own_color && f.depth == c->own_depth && f.tri_id == c->own_tri_id;
+        f.unowned_debt = f.world > 1 && own_targets(c);
         f.debt_tiles_y = a.tiles_y;
     }
     return FRR_OK;
@@ -698,12 +809,12 @@ int finish(frr_ctx *c)
         ++c->replays;
         for (const Cmd &m : todo) {
             // what the caller set between the commands travels with them
-            c->fs.color = m.pre.color; c->fs.depth = m.pre.depth; c->fs.tri_id = m.pre.tri_id;
+            c->fs.color = m.pre.color; c->fs.depth = m.pre.depth; c->fs.tri_id = m.pre.tri_id; c->fs.tset = m.pre.tset;
             c->fs.rank = m.pre.rank; c->fs.world = m.pre.world; c->fs.part_blocked = m.pre.part_blocked;
             if ((rc = exec_cmd(c, m)) != FRR_OK) { c->in_replay = false; return rc; }
         }
         c->in_replay = false;
-        c->fs.color = now.color; c->fs.depth = now.depth; c->fs.tri_id = now.tri_id;
+        c->fs.color = now.color; c->fs.depth = now.depth; c->fs.tri_id = now.tri_id; c->fs.tset = now.tset;
         c->fs.rank = now.rank; c->fs.world = now.world; c->fs.part_blocked = now.part_blocked;
         if ((rc = settle(c)) != FRR_OK) return rc;
     }
@@ -731,6 +842,7 @@ int frr_vs_input_floats(int vs_id)
     case FRR_VS_PHONG: return VSInfo<FRR_VS_PHONG>::NF;
     case FRR_VS_GOURAUD: return VSInfo<FRR_VS_GOURAUD>::NF;
     }
+    if (const UserShader *us = user_shader(vs_id)) return us->nf;
     return FRR_ERR_INVALID;
 }
 int frr_vs_num_varyings(int vs_id)
@@ -741,6 +853,7 @@ int frr_vs_num_varyings(int vs_id)
     case FRR_VS_PHONG: return VSInfo<FRR_VS_PHONG>::K;
     case FRR_VS_GOURAUD: return VSInfo<FRR_VS_GOURAUD>::K;
     }
+    if (const UserShader *us = user_shader(vs_id)) return us->K;
     return FRR_ERR_INVALID;
 }
 
@@ -761,19 +874,29 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     c->device = device; c->W = width; c->H = height;
     if (stream) c->stream = (hipStream_t)stream;
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FRR_ERR_HIP; } c->own_stream = true; }
-    if (hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking) != hipSuccess) { frr_destroy(c); return FRR_ERR_HIP; }
+    {
+        // geometry + binning are short and HBM-bound; beside a tile kernel that fills every workgroup slot they would get
+        // slots only as its workgroups retire (measured: 27 -> 88 us), so their stream has the higher priority
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char *pe = getenv("FRR_GSTREAM_PRIO");   // dev: 0 = default priority
+        const int prio = (pe && atoi(pe) == 0) ? 0 : hi;
+        if (hipStreamCreateWithPriority(&c->gstream, hipStreamNonBlocking, prio) != hipSuccess) { frr_destroy(c); return FRR_ERR_HIP; }
+    }
     const size_t npx = (size_t)width * height;
-    bool ok = hipMalloc((void **)&c->own_color, npx * 4) == hipSuccess && hipMalloc((void **)&c->own_depth, npx * 4) == hipSuccess &&
-              hipMalloc((void **)&c->own_tri_id, npx * 4) == hipSuccess && hipMalloc((void **)&c->cnt, sizeof(Counters)) == hipSuccess;
+    bool ok = hipMalloc((void **)&c->own_color[0], npx * 4) == hipSuccess && hipMalloc((void **)&c->own_depth[0], npx * 4) == hipSuccess &&
+              hipMalloc((void **)&c->own_tri_id[0], npx * 4) == hipSuccess && hipMalloc((void **)&c->cnt, sizeof(Counters)) == hipSuccess;
     c->max_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
     ok = ok && hipMalloc((void **)&c->tile_counts, (c->max_tiles + 1) * 4) == hipSuccess &&
          hipMalloc((void **)&c->tile_offsets, (c->max_tiles + 1) * 4) == hipSuccess &&
          hipMalloc((void **)&c->tile_cursor, (c->max_tiles + 1) * 4) == hipSuccess;
-    for (auto &e : c->ev_tile) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    for (GeomSet &S : c->gset) ok = ok && hipEventCreateWithFlags(&S.reader_ev, hipEventDisableTiming) == hipSuccess;
+    for (BinSet &B : c->bset) ok = ok && hipEventCreateWithFlags(&B.reader_ev, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_t2, hipEventDisableTiming) == hipSuccess;
     for (auto &e : c->ev_bin) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     if (!ok) { frr_destroy(c); return FRR_ERR_NOMEM; }
-    c->fs.color = c->own_color; c->fs.depth = c->own_depth; c->fs.tri_id = c->own_tri_id;
+    c->fs.color = c->own_color[0]; c->fs.depth = c->own_depth[0]; c->fs.tri_id = c->own_tri_id[0];
     {
         // tables of frame 0 (no frame has that number), no failed command
         memset(&c->hc, 0, sizeof c->hc);
@@ -781,9 +904,9 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
         if (hipMemcpy(c->cnt, &c->hc, sizeof(Counters), hipMemcpyHostToDevice) != hipSuccess) { frr_destroy(c); return FRR_ERR_HIP; }
     }
     (void)hipMemsetAsync(c->tile_counts, 0, (c->max_tiles + 1) * 4, c->stream);
-    (void)hipMemsetAsync(c->own_color, 0, npx * 4, c->stream);      // FrameBuffer::new zero-fills (renderer.rs:423)
-    (void)hipMemsetAsync(c->own_depth, 0, npx * 4, c->stream);
-    (void)hipMemsetAsync(c->own_tri_id, 0xFF, npx * 4, c->stream);
+    (void)hipMemsetAsync(c->own_color[0], 0, npx * 4, c->stream);      // FrameBuffer::new zero-fills (renderer.rs:423)
+    (void)hipMemsetAsync(c->own_depth[0], 0, npx * 4, c->stream);
+    (void)hipMemsetAsync(c->own_tri_id[0], 0xFF, npx * 4, c->stream);
     for (auto &e : c->ev) (void)hipEventCreate(&e);
     memset(&c->uni, 0, sizeof c->uni);
     frr_set_identity(c->uni.model); frr_set_identity(c->uni.view); frr_set_identity(c->uni.proj);
@@ -802,11 +925,14 @@ void frr_destroy(frr_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->gstream) (void)hipStreamSynchronize(c->gstream);
+    if (c->tstream2) (void)hipStreamSynchronize(c->tstream2);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
-    std::vector<void *> ptrs = {c->own_color, c->own_depth, c->own_tri_id, c->cnt, c->tile_counts, c->tile_offsets, c->tile_cursor};
+    for (auto &um : c->user_modules) if (um.second.mod) (void)hipModuleUnload(um.second.mod);
+    std::vector<void *> ptrs = {c->own_color[0], c->own_depth[0], c->own_tri_id[0], c->own_color[1], c->own_depth[1], c->own_tri_id[1],
+                                c->cnt, c->tile_counts, c->tile_offsets, c->tile_cursor};
     for (GeomSet &S : c->gset) for (void *p : {(void *)S.block_sums, (void *)S.block_prefix, (void *)S.tinfo, (void *)S.fanbase, (void *)S.fan_okey, (void *)S.recs,
                                                (void *)S.vary, (void *)S.pbox, (void *)S.bcount, (void *)S.clipq}) ptrs.push_back(p);
     for (BinSet &B : c->bset) for (void *p : {(void *)B.bins, (void *)B.bins2, (void *)B.bin_matrix}) ptrs.push_back(p);
@@ -815,11 +941,14 @@ void frr_destroy(frr_ctx *c)
     if (c->dbg_tiles) (void)hipFree(c->dbg_tiles);
 #endif
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
-    for (auto &e : c->ev_tile) if (e) (void)hipEventDestroy(e);
+    for (GeomSet &S : c->gset) if (S.reader_ev) (void)hipEventDestroy(S.reader_ev);
+    for (BinSet &B : c->bset) if (B.reader_ev) (void)hipEventDestroy(B.reader_ev);
+    if (c->ev_t2) (void)hipEventDestroy(c->ev_t2);
     for (auto &e : c->ev_bin) if (e) (void)hipEventDestroy(e);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->gstream) (void)hipStreamDestroy(c->gstream);
+    if (c->tstream2) (void)hipStreamDestroy(c->tstream2);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -840,6 +969,7 @@ int frr_set_option(frr_ctx *c, const char *name, int64_t v)
     else if (n == "bin_capacity") { if (v < 0) return fail(c, FRR_ERR_INVALID, "bin_capacity >= 0"); c->bin_cap_init = (size_t)v; }
     else if (n == "fan_capacity") { if (v < 0) return fail(c, FRR_ERR_INVALID, "fan_capacity >= 0"); c->fan_cap_init = (size_t)v; }
     else if (n == "overlap") { c->overlap = v != 0; c->need_join = true; }
+    else if (n == "frames_in_flight") { if (v != 1 && v != 2) return fail(c, FRR_ERR_INVALID, "frames_in_flight: 1 or 2"); c->frames_in_flight = (int)v; }
     else return fail(c, FRR_ERR_INVALID, "unknown option");
     return FRR_OK;
 }
@@ -859,27 +989,35 @@ int frr_set_partition_layout(frr_ctx *c, int blocked)
     return FRR_OK;
 }
 // owned tile rows of a window of `wh` pixel rows, by the same rule the kernels use (owns_tile_row)
-static int owned_band(const frr_ctx *c, int64_t wh, int band, int32_t *row0, int32_t *row1)
+static int owned_band_of(int rank, int world, bool blocked, int64_t wh, int band, int32_t *row0, int32_t *row1)
 {
-    const FrameState &f = c->fs;
     const int tiles_y = (int)((wh + TILE - 1) / TILE);
-    if (f.world <= 1) {
-        if (row0) { *row0 = 0; *row1 = (int32_t)wh; }
+    if (world <= 1) {
+        if (row0 && band == 0) { *row0 = 0; *row1 = (int32_t)wh; }
         return wh > 0 ? 1 : 0;
     }
-    if (f.part_blocked) {
+    if (blocked) {
         int t0, t1;
-        blocked_rows(tiles_y, f.rank, f.world, &t0, &t1);
+        blocked_rows(tiles_y, rank, world, &t0, &t1);
         if (t1 <= t0) return 0;
-        if (row0) { *row0 = t0 * TILE; *row1 = (int32_t)std::min<int64_t>(wh, (int64_t)t1 * TILE); }
+        if (row0 && band == 0) { *row0 = t0 * TILE; *row1 = (int32_t)std::min<int64_t>(wh, (int64_t)t1 * TILE); }
         return 1;
     }
-    const int n = tiles_y > f.rank ? (tiles_y - f.rank + f.world - 1) / f.world : 0;
+    const int n = tiles_y > rank ? (tiles_y - rank + world - 1) / world : 0;
     if (row0 && band < n) {
-        const int ty = f.rank + band * f.world;
+        const int ty = rank + band * world;
         *row0 = ty * TILE; *row1 = (int32_t)std::min<int64_t>(wh, (int64_t)(ty + 1) * TILE);
     }
     return n;
+}
+static int owned_band(const frr_ctx *c, int64_t wh, int band, int32_t *row0, int32_t *row1)
+{
+    return owned_band_of(c->fs.rank, c->fs.world, c->fs.part_blocked, wh, band, row0, row1);
+}
+int frr_partition_rows(int32_t y0, int32_t y1, int rank, int world, int blocked, int32_t band, int32_t *row0, int32_t *row1)
+{
+    if (y0 > y1 || world < 1 || rank < 0 || rank >= world || band < 0 || (row0 == nullptr) != (row1 == nullptr)) return FRR_ERR_INVALID;
+    return owned_band_of(rank, world, blocked != 0, (int64_t)y1 - y0, band, row0, row1);
 }
 int frr_owned_band_count(const frr_ctx *c, int32_t y0, int32_t y1)
 {
@@ -906,15 +1044,17 @@ int frr_bind_targets(frr_ctx *c, void *color, void *depth, void *tri_id)
 {
     if (!c) return FRR_ERR_INVALID;
     { int rc = settle(c); if (rc != FRR_OK) return rc; } // a pending clear belongs to the targets bound when it was issued
-    c->fs.color = color ? (uint8_t *)color : c->own_color;
-    c->fs.depth = depth ? (float *)depth : c->own_depth;
-    c->fs.tri_id = tri_id ? (uint32_t *)tri_id : c->own_tri_id;
+    { int rc = join_tile_streams(c); if (rc != FRR_OK) return rc; }
+    c->fs.color = color ? (uint8_t *)color : c->own_color[c->fs.tset];
+    c->fs.depth = depth ? (float *)depth : c->own_depth[c->fs.tset];
+    c->fs.tri_id = tri_id ? (uint32_t *)tri_id : c->own_tri_id[c->fs.tset];
     return FRR_OK;
 }
 int frr_target_ptrs(frr_ctx *c, void **color, void **depth, void **tri_id)
 {
     if (!c) return FRR_ERR_INVALID;
-    { int rc = settle(c); if (rc != FRR_OK) return rc; } // the caller is about to look at them
+    { int rc = settle(c); if (rc != FRR_OK) return rc; } // the caller is about to look at them ...
+    { int rc = join_tile_streams(c); if (rc != FRR_OK) return rc; } // ... from its stream
     if (color) *color = c->fs.color;
     if (depth) *depth = c->fs.depth;
     if (tri_id) *tri_id = c->fs.tri_id;
@@ -987,6 +1127,66 @@ int frr_set_uniforms(frr_ctx *c, const frr_uniforms *u)
     return FRR_OK;
 }
 
+int frr_set_user_uniforms(frr_ctx *c, const float *values, int n)
+{
+    if (!c || n < 0 || n > FRR_MAX_USER_UNIFORMS || (n && !values)) return fail(c, FRR_ERR_INVALID, "user uniforms: at most FRR_MAX_USER_UNIFORMS floats");
+    memset(c->duni.user, 0, sizeof c->duni.user);
+    if (n) memcpy(c->duni.user, values, (size_t)n * sizeof(float));
+    return FRR_OK;
+}
+
+int frr_shader_register(frr_ctx *c, const char *hip_source, int vs_input_floats, int num_varyings, int *shader_id)
+{
+    if (!hip_source || !shader_id || vs_input_floats < 1 || vs_input_floats > 64 || num_varyings < 0 || num_varyings > FRR_MAX_VARYINGS)
+        return fail(c, FRR_ERR_INVALID, "bad shader description (1..64 input floats, 0..FRR_MAX_VARYINGS varyings)");
+    // the program: fixed-width types (hiprtc keeps them in a namespace), this shader's shape, the device header, the
+    // user's functions, the kernels -- the very headers libfrr_hip.so itself was built from
+    std::string src = "using __hip_internal::int8_t; using __hip_internal::uint8_t; using __hip_internal::int16_t; using __hip_internal::uint16_t;\n"
+                      "using __hip_internal::int32_t; using __hip_internal::uint32_t; using __hip_internal::int64_t; using __hip_internal::uint64_t;\n"
+                      "typedef unsigned long uintptr_t;\n#define FRR_USER_SHADER 1\n";
+    src += "#define FRR_USER_NF " + std::to_string(vs_input_floats) + "\n#define FRR_USER_K " + std::to_string(num_varyings) + "\n";
+    src += "#include \"frr_device.h\"\n#line 1 \"user_shader\"\n";
+    src += hip_source;
+    src += "\n#include \"frr_kernels.h\"\n";
+    const char *hdr_txt[] = {frr_src_device_h, frr_src_exact_h, frr_src_kernels_h, frr_src_raster_h, frr_src_frr_h};
+    const char *hdr_name[] = {"frr_device.h", "frr_exact.h", "frr_kernels.h", "frr_raster.h", "../../include/frr.h"};
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "frr_user_program.hip", 5, hdr_txt, hdr_name) != HIPRTC_SUCCESS) return fail(c, FRR_ERR_HIP, "hiprtcCreateProgram");
+    UserShader *us = new UserShader();
+    us->nf = vs_input_floats; us->K = num_varyings;
+    const std::string U = std::to_string(FRR_SHADER_USER_BASE), Ks = std::to_string(num_varyings);
+    std::vector<std::string> exprs = {"frr::k_geom_single<" + U + ">", "frr::k_geom_clip<" + U + ">"};
+    for (int cnt = 0; cnt < 2; ++cnt)
+        for (int sh = 0; sh < 6; ++sh)
+            exprs.push_back("frr::k_raster_span<" + Ks + ", " + U + ", " + (cnt ? "true" : "false") + ", " + std::to_string(kSpanShapes[sh][0]) + ", " + std::to_string(kSpanShapes[sh][1]) + ">");
+    for (const std::string &e : exprs) (void)hiprtcAddNameExpression(prog, e.c_str());
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function"};
+    const hiprtcResult res = hiprtcCompileProgram(prog, 6, opts);
+    if (res != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        (void)hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n + 1, '\0');
+        if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
+        (void)hiprtcDestroyProgram(&prog);
+        delete us;
+        return fail(c, FRR_ERR_UNSUPPORTED, std::string("user shader does not compile:\n") + log.c_str());
+    }
+    bool ok = true;
+    auto lowered = [&](const std::string &e) { const char *n = nullptr; ok = ok && hiprtcGetLoweredName(prog, e.c_str(), &n) == HIPRTC_SUCCESS && n; return std::string(n ? n : ""); };
+    us->geom = lowered(exprs[0]); us->clip = lowered(exprs[1]);
+    for (int cnt = 0; cnt < 2; ++cnt)
+        for (int sh = 0; sh < 6; ++sh) us->span[cnt][sh] = lowered(exprs[2 + (size_t)cnt * 6 + sh]);
+    size_t cs = 0;
+    ok = ok && hiprtcGetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs;
+    if (ok) { us->code.resize(cs); ok = hiprtcGetCode(prog, us->code.data()) == HIPRTC_SUCCESS; }
+    (void)hiprtcDestroyProgram(&prog);
+    if (!ok) { delete us; return fail(c, FRR_ERR_HIP, "hiprtc: no code object"); }
+    std::lock_guard<std::mutex> lk(g_shader_mu);
+    g_shaders.push_back(us);
+    *shader_id = FRR_SHADER_USER_BASE + (int)g_shaders.size() - 1;
+    return FRR_OK;
+}
+
 int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
 {
     if (!c || !rgba) return FRR_ERR_INVALID;
@@ -1004,6 +1204,20 @@ int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
     f.geom_ntris = 0;          // the setup list of a preceding frr_geometry is gone (frr_raster then draws nothing)
     f.scan_pending = false;
     f.unowned_debt = false;    // superseded: the clear covers every row
+    if (c->frames_in_flight == 2 && own_targets(c)) {
+        // own targets: this frame takes the other set (and its tile kernels the other stream), so that it need not wait
+        // for the previous frame's tile kernel to drain; the old set's content is dead (the clear overwrites everything)
+        const int t = f.tset ^ 1;
+        if (!c->own_color[t]) {
+            const size_t npx = (size_t)c->W * c->H;
+            bool ok = hipMalloc((void **)&c->own_color[t], npx * 4) == hipSuccess && hipMalloc((void **)&c->own_depth[t], npx * 4) == hipSuccess &&
+                      hipMalloc((void **)&c->own_tri_id[t], npx * 4) == hipSuccess;
+            ok = ok && (c->tstream2 || hipStreamCreateWithFlags(&c->tstream2, hipStreamNonBlocking) == hipSuccess);
+            if (!ok) return fail(c, FRR_ERR_NOMEM, "second target set");
+        }
+        f.tset = t;
+        f.color = c->own_color[t]; f.depth = c->own_depth[t]; f.tri_id = c->own_tri_id[t];
+    }
     if (c->clear_eager) { f.clear_pending = false; return clear_now(c, packed, depth); }
     f.clear_rgba = packed; f.clear_depth = depth;
     f.clear_pending = true;
@@ -1037,7 +1251,10 @@ static int raster_check(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y
     if (ww > 0 && wh > 0 && (x1 <= 0 || (wh - 1) * (int64_t)x1 + ww > (int64_t)c->W * c->H))
         return fail(c, FRR_ERR_INVALID, "depth index (cy-y0)*x1+(cx-x0) would leave the depth buffer (renderer.rs:362)");
     const int K = frr_vs_num_varyings(f.geom_vs);
-    if ((ps_id == FRR_PS_COLOR && K != 3) || ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && K != 8) || ps_id < 0 || ps_id > FRR_PS_BLINN)
+    if (ps_id >= FRR_SHADER_USER_BASE || f.geom_vs >= FRR_SHADER_USER_BASE) {
+        if (ps_id != f.geom_vs || !user_shader(ps_id)) return fail(c, FRR_ERR_INVALID, "a user shader id stands for its vertex AND pixel shader: draw the mesh with the id it was uploaded with");
+        if (c->raster_sweep) return fail(c, FRR_ERR_UNSUPPORTED, "the brute-force tile kernel (option raster_sweep) is not generated for user shaders");
+    } else if ((ps_id == FRR_PS_COLOR && K != 3) || ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && K != 8) || ps_id < 0 || ps_id > FRR_PS_BLINN)
         return fail(c, FRR_ERR_INVALID, "pixel shader does not match the vertex shader's varyings");
     if ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && !c->duni.tex) return fail(c, FRR_ERR_INVALID, "no texture bound to uniforms.texture_slot");
     {
@@ -1185,6 +1402,9 @@ int frr_get_stats(frr_ctx *c, frr_stats *out)
 int frr_event_record(frr_ctx *c, int slot)
 {
     if (!c || slot < 0 || slot >= 16) return FRR_ERR_INVALID;
+    // (a measuring call: the caller's stream first waits for the ctx's other streams, so that the event brackets whole frames)
+    if (c->overlap) { HIP_TRY(c, hipEventRecord(c->ev_join, c->gstream)); HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
+    { int rcj = join_tile_streams(c); if (rcj != FRR_OK) return rcj; }
     HIP_TRY(c, hipEventRecord(c->ev[slot], c->stream));
     c->ev_set[slot] = true;
     return FRR_OK;

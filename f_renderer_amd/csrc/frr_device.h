@@ -129,6 +129,7 @@ struct DevUniforms {
     float flat_color[4];
     const uint8_t *tex;
     uint32_t tex_w, tex_h;
+    float user[FRR_MAX_USER_UNIFORMS];   // frr_set_user_uniforms: what a user shader's closure would have captured
 };
 
 struct GeomArgs {
@@ -290,9 +291,34 @@ template <> struct VSInfo<FRR_VS_CLIP_COLOR> { static constexpr int NF = 7, K = 
 template <> struct VSInfo<FRR_VS_PHONG> { static constexpr int NF = 8, K = 8; };
 template <> struct VSInfo<FRR_VS_GOURAUD> { static constexpr int NF = 8, K = 3; };
 
+} // namespace frr
+#ifdef FRR_USER_SHADER
+// User shaders (frr_shader_register): the program text hiprtc compiles is  this header, the user's source, the kernels.
+// The user's source defines these two functions -- the bodies of the reference's vertex_shader / pixel_shader closures
+// (renderer.rs:105,110 / :273,283) -- with everything above (glam pieces, frr_exact.h) and sample_2d below to build on.
+__device__ void frr_user_vs(const frr::DevUniforms &u, const float *in, float pos[4], float *ctx);
+__device__ void frr_user_ps(const frr::DevUniforms &u, const float *ctx, float out[4], const float *u8lut);
+#endif
+namespace frr {
+#ifdef FRR_USER_SHADER
+template <> struct VSInfo<FRR_SHADER_USER_BASE> { static constexpr int NF = FRR_USER_NF, K = FRR_USER_K; };
+#endif
+
 template <int VS, bool WITH_CTX>
 __device__ __forceinline__ void run_vs(const DevUniforms &u, const float *__restrict__ in, float pos[4], float *ctx)
 {
+#ifdef FRR_USER_SHADER
+    if constexpr (VS >= FRR_SHADER_USER_BASE) {
+        float c[VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1];
+#pragma unroll
+        for (int k = 0; k < VSInfo<VS>::K; ++k) c[k] = 0.0f;       // T::default() (renderer.rs:113)
+        frr_user_vs(u, in, pos, c);
+        if constexpr (WITH_CTX) {
+#pragma unroll
+            for (int k = 0; k < VSInfo<VS>::K; ++k) ctx[k] = c[k];
+        }
+    } else
+#endif
     if constexpr (VS == FRR_VS_CLIP) {
         float4 v = *reinterpret_cast<const float4 *>(in);
         pos[0] = v.x; pos[1] = v.y; pos[2] = v.z; pos[3] = v.w;
@@ -501,6 +527,11 @@ __device__ __forceinline__ void sample_2d(const DevUniforms &u, float uu, float 
 template <int PS>
 __device__ __forceinline__ void run_ps(const DevUniforms &u, const float *ctx, float out[4], const float *u8lut = nullptr)
 {
+#ifdef FRR_USER_SHADER
+    if constexpr (PS >= FRR_SHADER_USER_BASE) {
+        frr_user_ps(u, ctx, out, u8lut);
+    } else
+#endif
     if constexpr (PS == FRR_PS_FLAT) {
         out[0] = u.flat_color[0]; out[1] = u.flat_color[1]; out[2] = u.flat_color[2]; out[3] = u.flat_color[3];
     } else if constexpr (PS == FRR_PS_COLOR) {

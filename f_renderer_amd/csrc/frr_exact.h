@@ -5,8 +5,14 @@
 // preserved (hipcc default), so `a*b+c` below means two roundings exactly as in the reference
 // (/root/reference/f_renderer/src/renderer.rs; Rust never contracts or reassociates).
 #pragma once
+#ifndef __HIPCC_RTC__      // (hiprtc -- user shaders, frr_shader_register -- brings the HIP device headers and the fixed-width types itself)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
+#ifndef INT32_MAX
+#define INT32_MAX 2147483647
+#define INT32_MIN (-2147483647 - 1)
+#endif
 
 #define FRR_HD __host__ __device__ __forceinline__
 

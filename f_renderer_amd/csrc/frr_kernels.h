@@ -4,7 +4,9 @@
 // binning: one segmented LDS multi-split launch ; raster+resolve per 32x32 tile }.  See DESIGN.md for the roofline of each kernel.
 #pragma once
 #include "frr_device.h"
+#ifndef __HIPCC_RTC__
 #include <type_traits>
+#endif
 
 namespace frr {
 

@@ -17,7 +17,9 @@
 //                  which is exact under wrapping arithmetic.
 #pragma once
 #include "frr_device.h"
+#ifndef __HIPCC_RTC__
 #include <type_traits>
+#endif
 
 namespace frr {
 
@@ -542,7 +544,7 @@ template <int K, int PS, bool COUNT, int NW, int OCC>
 __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevUniforms u, int win_safe)
 {
     constexpr int B = NW <= 3 ? LIGHT_B : (OCC >= 8 || NW >= 16) ? 16 : SPAN_BATCH; // staged triangles per wave (LDS budget: 8 workgroups per CU; 64 KiB of static LDS at NW = 16)
-    constexpr bool TEXTURED = PS == FRR_PS_PHONG || PS == FRR_PS_BLINN;
+    constexpr bool TEXTURED = PS == FRR_PS_PHONG || PS == FRR_PS_BLINN || PS >= FRR_SHADER_USER_BASE;   // (the u8 -> float table of sample_2d)
     using L = SpanLds<NW, B>;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[L::bytes(TEXTURED)];
     unsigned long long *const s_key = reinterpret_cast<unsigned long long *>(s_raw + L::KEY);

@@ -119,7 +119,7 @@ def _options_from_env():
         o["raster_sweep"] = 1
     for var, name in (("FRR_RASTER_NW", "raster_nw"), ("FRR_RASTER_OCC", "raster_occ"), ("FRR_BIN_G", "bin_chunks"),
                       ("FRR_ENT_SLOT", "tile_slot_records"), ("FRR_BIN_CAP", "bin_capacity"), ("FRR_FAN_CAP", "fan_capacity"),
-                      ("FRR_CLIP_QUEUE", "clip_queue"), ("FRR_OVERLAP", "overlap")):
+                      ("FRR_CLIP_QUEUE", "clip_queue"), ("FRR_OVERLAP", "overlap"), ("FRR_FRAMES_IN_FLIGHT", "frames_in_flight")):
         if e.get(var):
             o[name] = int(e[var])
     if e.get("FRR_CLEAR") == "eager":
@@ -220,6 +220,19 @@ class Renderer:
         if texture_slot is not None:
             u.texture_slot = int(texture_slot)
         self._check(self._lib.frr_set_uniforms(self._ctx, C.byref(u)))
+
+    def register_shader(self, hip_source, vs_input_floats, num_varyings):
+        """The reference's closure API (renderer.rs:105,283) as text: HIP source defining frr_user_vs / frr_user_ps
+        (include/frr.h: user shaders), compiled at run time into the library's kernels.  Returns the shader id to pass as
+        vs_id to upload_mesh and as pixel_shader to rasterization / draw."""
+        sid = C.c_int()
+        self._check(self._lib.frr_shader_register(self._ctx, hip_source.encode(), int(vs_input_floats), int(num_varyings), C.byref(sid)))
+        return sid.value
+
+    def set_user_uniforms(self, values):
+        """u.user[...] of the user shaders: what the reference's closures would have captured."""
+        v = np.ascontiguousarray(values, np.float32).reshape(-1)
+        self._check(self._lib.frr_set_user_uniforms(self._ctx, _fp(v), v.size))
 
     def set_partition(self, rank, world, blocked=False):
         """Tile-row ownership of a multi-GPU rank: interleaved rows (ty % world == rank) or, blocked=True,

@@ -20,7 +20,9 @@
  */
 #ifndef FRR_H
 #define FRR_H
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -29,6 +31,8 @@ extern "C" {
 #define FRR_ABI_VERSION 3
 #define FRR_MAX_VARYINGS 16
 #define FRR_MAX_TEXTURES 4
+#define FRR_MAX_USER_UNIFORMS 32 /* f32 a user shader receives (frr_set_user_uniforms) */
+#define FRR_SHADER_USER_BASE 64  /* ids of user shaders (frr_shader_register) start here */
 #define FRR_MAX_OUT_TRIS 19 /* 3 + 18 clip vertices -> 19 fan triangles (renderer.rs:150-171,245-264) */
 
 typedef struct frr_ctx frr_ctx;
@@ -62,6 +66,35 @@ typedef enum frr_ps {
     FRR_PS_PHONG = 3, /* phong.rs:133-154 (reflect-vector Phong x bilinear texture) */
     FRR_PS_BLINN = 4  /* half-vector variant of the same (not in the reference) */
 } frr_ps;
+
+/* ---- user shaders -------------------------------------------------------------------------------------------
+ * The reference's shaders are closures: `vertex_shader: &F` with F: Fn(&VSUniform, &VSInput, &mut ShaderContext) -> Vec4
+ * (renderer.rs:105,110,116) and `pixel_shader: &F` with F: Fn(&PSUniform, &ShaderContext) -> Vec4 (:273,283,380), over any
+ * varying type that is a real vector space (Add + Sub + Mul<f32> + Copy + Default, :97-102).  A closure cannot cross this
+ * boundary as a function pointer -- it has to run on the GPU inside the geometry and tile kernels -- so it crosses as
+ * TEXT: HIP device source that the library compiles at run time (hiprtc, gfx950, -ffp-contract=off like the library
+ * itself) into its own kernels.  The source defines, at global scope,
+ *
+ *   __device__ void frr_user_vs(const frr::DevUniforms &u, const float *in, float pos[4], float *ctx);
+ *       in: vs_input_floats f32 of one vertex;  ctx: num_varyings f32, zero on entry (T::default());  pos: clip xyzw
+ *   __device__ void frr_user_ps(const frr::DevUniforms &u, const float *ctx, float out[4], const float *u8lut);
+ *       ctx: the interpolated varyings (renderer.rs:374-378);  out: the Vec4 that vec4_to_u8_array quantises (:7-14)
+ *
+ * and may use what the built-in shaders are written with (f_renderer_amd/csrc/frr_device.h, frr_exact.h, namespace frr):
+ * u.mvp / u.model (column-major), u.view_pos, u.light_pos, u.light_color, u.ambient_strength, u.specular_strength,
+ * u.flat_color, u.user[FRR_MAX_USER_UNIFORMS] (frr_set_user_uniforms: what the closure would have captured),
+ * frr::mat4_mul_vec4, frr::dot3, frr::normalize3 (glam's operation order), frr::f32_max, frr::recip_exact, and
+ * frr::sample_2d(u, uu, vv, rgba_out, u8lut) (FrameBuffer::sample_2d of the texture in uniforms.texture_slot, :516-538).
+ * fp32 expressions keep their written association (no FMA contraction), as in the reference's Rust.
+ *
+ * frr_shader_register returns one id >= FRR_SHADER_USER_BASE that stands for the pair: pass it as vs_id to
+ * frr_mesh_upload / frr_mesh_bind_device and as ps_id to frr_raster / frr_draw of that mesh.  ctx may be NULL (compile
+ * only: the registry is per process; a ctx loads the code object on first use).  A source that does not compile:
+ * FRR_ERR_UNSUPPORTED, with the compiler's log in frr_last_error(ctx).  The brute-force tile kernel (option raster_sweep)
+ * is not generated for user shaders. */
+int frr_shader_register(frr_ctx *ctx, const char *hip_source, int vs_input_floats, int num_varyings, int *shader_id);
+/* u.user[0..n) for the draws issued from now on (n <= FRR_MAX_USER_UNIFORMS; travels with each draw like frr_uniforms) */
+int frr_set_user_uniforms(frr_ctx *ctx, const float *values, int n);
 
 /* VSUniform (phong.rs:26-31) + PSUniform (phong.rs:41-47) + light consts (phong.rs:128-132).
  * Matrices column-major like glam::Mat4::from_cols_array (matrix_util.rs:5-7). */
@@ -131,6 +164,10 @@ int frr_set_partition_layout(frr_ctx *ctx, int blocked);
  * frr_status. */
 int frr_owned_band_count(const frr_ctx *ctx, int32_t y0, int32_t y1);
 int frr_owned_rows(const frr_ctx *ctx, int32_t y0, int32_t y1, int32_t band, int32_t *row0, int32_t *row1);
+/* The same rule for ANY rank, without a ctx: what the root of the final-image exchange posts its receives with
+ * (examples/gather_rccl.cpp).  Returns the number of bands rank `rank` of `world` owns in a window of height_range
+ * (y0, y1) (negative: bad argument); if row0/row1 are not NULL and band is in range they receive band `band`. */
+int frr_partition_rows(int32_t y0, int32_t y1, int rank, int world, int blocked, int32_t band, int32_t *row0, int32_t *row1);
 /* frr_stats.frag_covered is exact while counting is enabled (default).  Disabling it lets the tile
  * kernel drop whole triangles by hierarchical early-z before their coverage is known (images are
  * identical either way; only the statistic stops being maintained). */

@@ -102,3 +102,18 @@ def test_header_is_plain_c99(tmp_path):
     src.write_text('#include "frr.h"\nint use(frr_ctx *c) { frr_stats s; return frr_get_stats(c, &s) + frr_abi_version(); }\n')
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+
+
+def test_user_shader_text_compiles_without_a_gpu():
+    """frr_shader_register with no ctx: hiprtc compiles the user's functions into the library's own geometry and tile kernels
+    (the embedded headers are the ones libfrr_hip.so was built from) for gfx950; a broken source is refused, not crashed on."""
+    import ctypes as C
+    import f_renderer_amd as fr
+    from . import user_shaders
+    L = fr.lib()
+    sid = C.c_int(-1)
+    assert L.frr_shader_register(None, user_shaders.VERTEX_COLOR.encode(), 7, 3, C.byref(sid)) == fr.FRR_OK
+    assert sid.value >= 64 and L.frr_vs_input_floats(sid.value) == 7 and L.frr_vs_num_varyings(sid.value) == 3
+    bad = C.c_int(-1)
+    assert L.frr_shader_register(None, user_shaders.BROKEN.encode(), 4, 0, C.byref(bad)) == fr.FRR_ERR_UNSUPPORTED and bad.value == -1
+    assert L.frr_shader_register(None, user_shaders.VERTEX_COLOR.encode(), 0, 3, C.byref(bad)) == fr.FRR_ERR_INVALID

@@ -10,11 +10,33 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build():
+def _build(target="phong_headless"):
     import f_renderer_amd as fr
     fr.build()
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s", "phong_headless"])
-    return os.path.join(ROOT, "examples", "phong_headless")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s", target])
+    return os.path.join(ROOT, "examples", target)
+
+
+def test_rccl_gather_example_compiles():
+    """CPU: the native final-image exchange (examples/gather_rccl.cpp: frr_owned_rows + frr_target_ptrs + ncclSend/ncclRecv,
+    one process per GPU) compiles and links against the C ABI and /opt/rocm's RCCL; without a GPU it fails loudly."""
+    exe = _build("gather_rccl")
+    assert os.path.exists(exe)
+    import torch
+    if not torch.cuda.is_available():
+        p = subprocess.run([exe], capture_output=True, text=True)
+        assert p.returncode != 0
+
+
+@pytest.mark.gpu
+def test_rccl_gather_example_runs_with_one_rank(tmp_path):
+    """One rank (this box has one GPU): RCCL communicator, partitioned draw, the exchange group, and the comparison of the
+    "gathered" image with frr_readback of an unpartitioned context -- the program exits 0 only if they are equal."""
+    exe = _build("gather_rccl")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([exe, "--width", "700", "--height", "333", "--tris", "30000", "--frames", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "EQUALS" in p.stdout
 
 
 def test_cpp_example_compiles_against_header():

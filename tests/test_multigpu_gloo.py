@@ -86,6 +86,34 @@ def test_band_gather_gloo(tmp_path, world, H, W):
     np.testing.assert_array_equal(np.load(out), full)
 
 
+def test_blocked_rows_agree_between_library_and_python():
+    """frr_partition_rows (what a native host posts its receives with) == multigpu.block_rows (what bench.py uses), every
+    rank owns something while there are rows to go round, and the blocks tile the window exactly once."""
+    import ctypes as C
+    import f_renderer_amd as fr
+    from f_renderer_amd.multigpu import block_rows, block_tile_rows
+    L = fr.lib()
+    for H in (1080, 2160, 4096, 333, 33, 1):
+        tiles_y = (H + 31) // 32
+        for world in (1, 2, 3, 4, 7, 8):
+            seen = 0
+            for rank in range(world):
+                a, b = C.c_int32(), C.c_int32()
+                n = L.frr_partition_rows(0, H, rank, world, 1, 0, C.byref(a), C.byref(b))
+                y0, y1 = block_rows(H, rank, world)
+                t0, t1 = block_tile_rows(tiles_y, rank, world)
+                assert n == (1 if t1 > t0 else 0)
+                assert (t1 > t0) or rank >= tiles_y            # nobody is left without rows while there are enough
+                if n:
+                    assert (a.value, b.value) == (y0, min(y1, H)) and a.value == seen
+                    seen = b.value
+            assert seen == H
+    a, b = C.c_int32(), C.c_int32()
+    assert [L.frr_partition_rows(0, 1080, r, 8, 1, 0, C.byref(a), C.byref(b)) and (b.value - a.value + 31) // 32 for r in range(8)] == [5, 5, 4, 4, 4, 4, 4, 4]
+    assert L.frr_partition_rows(0, 100, 1, 2, 0, 0, C.byref(a), C.byref(b)) == 2 and (a.value, b.value) == (32, 64)   # interleaved: bands
+    assert L.frr_partition_rows(5, 1, 0, 1, 0, 0, None, None) < 0
+
+
 def test_band_layout_matches_partition_rule():
     from f_renderer_amd.multigpu import band_layout, owned_tile_rows
     for H in (1080, 2160, 4096, 33, 1):
