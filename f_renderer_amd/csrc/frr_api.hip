@@ -86,12 +86,14 @@ struct GeomSet {
     uint32_t *bcount = nullptr; size_t bcount_cap = 0;          // [geometry blocks] dense binning entries per block (GeomArgs::bcount)
     uint2 *clipq = nullptr; size_t clipq_cap = 0;               // [input triangles] the clip kernel's queue (GeomArgs::clipq)
     hipEvent_t reader_ev = nullptr; bool reader_pending = false; // fires when the latest tile kernel that reads this set is done
+    hipStream_t reader_stream = nullptr;                         // ... on this stream
 };
 struct BinSet {
     uint4 *bins = nullptr; size_t bin_cap = 0;   // 16-byte cull records, one per (triangle, tile) pair
     uint4 *bins2 = nullptr; size_t bin2_cap = 0; // the same in near-first order per tile (tile kernel pre-pass)
     uint32_t *bin_matrix = nullptr; size_t bin_matrix_cap = 0; // [G][ntiles] per-chunk tile histograms
     hipEvent_t reader_ev = nullptr; bool reader_pending = false;
+    hipStream_t reader_stream = nullptr;
 };
 
 struct GeomFilter { bool active; int32_t y0, y1; int rank, world; bool blocked; };
@@ -111,7 +113,9 @@ struct FrameState {
     uint32_t clear_rgba = 0; float clear_depth = 0.0f;
     uint32_t frame_no = 1;         // frr_clear count (device statistics are tagged with it)
     uint64_t tris_in = 0; uint32_t draws = 0;   // statistics the host knows: inputs submitted / geometry passes since frr_clear
-    int gpar = 0, bpar = 0;        // parity of the latest geometry / raster pass (GeomSet / BinSet / GeomTab / BinTab)
+    int gpar = 0, bpar = 0;        // parity of the latest geometry / raster pass (device tables GeomTab / BinTab)
+    int gset = 0, bset = 0;        // workspace set of the latest geometry / raster pass (GeomSet / BinSet)
+    bool on_g = false;             // the latest geometry pass runs on the second stream (its binning follows it there)
     GeomFilter geom_filter = {false, 0, 0, 0, 1, false}; // tile-row ownership filter the latest setup list was built with (frr_draw on a partitioned ctx)
     uint32_t geom_fan_cap = 0;     // fan capacity the latest geometry pass was launched with
     uint32_t geom_nblocks = 0;
@@ -131,6 +135,7 @@ struct Cmd {
     // RASTER
     int ps = 0; int32_t x0 = 0, x1 = 0, y0 = 0, y1 = 0; bool count_frags = true;
     int par = 0;               // the parity it ran with (finish(): which table a failed command left behind)
+    int set = 0;               // RASTER: the BinSet it ran with
 };
 
 } // namespace
@@ -141,7 +146,8 @@ struct frr_ctx {
     hipStream_t stream = nullptr;   // the caller's stream (or a private one): tile kernels, clears, copies -- everything that touches the targets
     hipStream_t gstream = nullptr;  // private: geometry + binning of the next pass, beside the tile kernel of the current one
     bool own_stream = false;
-    bool overlap = true;            // option overlap: use gstream (else everything runs on `stream`)
+    int overlap = 2;                // option overlap: 0 never use gstream, 1 always, 2 (default) for passes with varyings (exec_geometry)
+    bool g_used = false;            // some pass has run on gstream since the streams were last drained (cross-stream events are needed)
     // The ctx's own frame targets: TWO sets.  A frame that starts with frr_clear on own targets takes the other set and
     // its tile kernels the other tile stream (tstream2 for set 1), so that the tile kernel of frame n + 1 fills the drain
     // of frame n's (2,040 tiles on 1,536 workgroup slots end with a third of the chip idle).  Nobody can look at own targets
@@ -151,7 +157,7 @@ struct frr_ctx {
     hipStream_t tstream2 = nullptr;  // tile kernels / clears of own target set 1
     hipEvent_t ev_t2 = nullptr;      // joins tstream2 into `stream`
     bool t2_dirty = false;           // tstream2 holds work `stream` has not waited for
-    int frames_in_flight = 2;        // option frames_in_flight (1: one set, one tile stream)
+    int frames_in_flight = 1;        // option frames_in_flight (1: one set, one tile stream; 2 was measured slower on every workload, profiles/r03_overlap_modes.txt)
     Counters *cnt = nullptr;
     FrameState fs;
     GeomSet gset[2];
@@ -218,7 +224,7 @@ int fail(frr_ctx *c, int code, const std::string &msg)
             return fail(c, FRR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
     } while (0)
 
-hipStream_t gstream_of(const frr_ctx *c) { return c->overlap ? c->gstream : c->stream; }
+
 // the stream of everything that touches the current frame targets
 bool own_targets(const frr_ctx *c)
 {
@@ -226,6 +232,10 @@ bool own_targets(const frr_ctx *c)
     return f.color == c->own_color[f.tset] && f.depth == c->own_depth[f.tset] && f.tri_id == c->own_tri_id[f.tset];
 }
 hipStream_t tstream_of(const frr_ctx *c) { return (c->tstream2 && c->fs.tset == 1 && own_targets(c)) ? c->tstream2 : c->stream; }
+// the stream of the latest geometry pass and of the binning that follows it: the second stream, or the targets' stream
+hipStream_t gstream_of(const frr_ctx *c) { return c->fs.on_g ? c->gstream : tstream_of(c); }
+// do passes ever run beside each other on this ctx (workspace sets then carry events)?
+bool multi_stream(const frr_ctx *c) { return c->g_used || c->tstream2 != nullptr; }
 
 // all streams idle
 int drain(frr_ctx *c)
@@ -234,6 +244,9 @@ int drain(frr_ctx *c)
     if (c->tstream2) HIP_TRY(c, hipStreamSynchronize(c->tstream2));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->t2_dirty = false;
+    c->g_used = false;
+    for (GeomSet &S : c->gset) S.reader_pending = false;
+    for (BinSet &B : c->bset) B.reader_pending = false;
     return FRR_OK;
 }
 // the caller's stream waits for the second tile stream: what the caller enqueues next sees every frame issued so far
@@ -264,14 +277,14 @@ template <class SET> int gstream_wait_readers(frr_ctx *c, SET &S)
 {
     if (!S.reader_pending) return FRR_OK;
     S.reader_pending = false;
-    if (gstream_of(c) == c->stream && !c->tstream2) return FRR_OK;   // one stream: already in order
+    if (S.reader_stream == gstream_of(c)) return FRR_OK;   // same stream: already in order
     HIP_TRY(c, hipStreamWaitEvent(gstream_of(c), S.reader_ev, 0));
     return FRR_OK;
 }
 // the second stream waits for everything the caller's stream holds so far (mesh data written by the caller)
 int gstream_join(frr_ctx *c)
 {
-    if (!c->overlap || !c->need_join) { c->need_join = false; return FRR_OK; }
+    if (!c->fs.on_g || !c->need_join) return FRR_OK;
     HIP_TRY(c, hipEventRecord(c->ev_join, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(c->gstream, c->ev_join, 0));
     c->need_join = false;
@@ -291,9 +304,9 @@ int tile_launched(frr_ctx *c, GeomSet &gs, BinSet &bs)
 {
     hipStream_t ts = tstream_of(c);
     if (ts == c->tstream2) c->t2_dirty = true;
-    if (gstream_of(c) == c->stream && !c->tstream2) return FRR_OK;   // one stream
-    HIP_TRY(c, hipEventRecord(gs.reader_ev, ts)); gs.reader_pending = true;
-    HIP_TRY(c, hipEventRecord(bs.reader_ev, ts)); bs.reader_pending = true;
+    if (!multi_stream(c)) return FRR_OK;   // everything has run on one stream so far
+    HIP_TRY(c, hipEventRecord(gs.reader_ev, ts)); gs.reader_pending = true; gs.reader_stream = ts;
+    HIP_TRY(c, hipEventRecord(bs.reader_ev, ts)); bs.reader_pending = true; bs.reader_stream = ts;
     return FRR_OK;
 }
 
@@ -424,7 +437,7 @@ int scan_now(frr_ctx *c)
     FrameState &f = c->fs;
     if (!f.scan_pending) return FRR_OK;
     hipStream_t st = gstream_of(c);
-    { ProfScope p(c, KID_GEOM_SCAN, st); hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, st, c->gset[f.gpar].block_sums, c->gset[f.gpar].block_prefix, f.geom_nblocks, c->cnt, f.gpar, f.geom_fan_cap, f.geom_seq, c->epoch); }
+    { ProfScope p(c, KID_GEOM_SCAN, st); hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, st, c->gset[f.gset].block_sums, c->gset[f.gset].block_prefix, f.geom_nblocks, c->cnt, f.gpar, f.geom_fan_cap, f.geom_seq, c->epoch); }
     HIP_TRY(c, hipGetLastError());
     f.scan_pending = false;
     return FRR_OK;
@@ -532,7 +545,13 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
     const int K = frr_vs_num_varyings(m.vs);
     const uint64_t nt = m.ntris;
     const int par = f.gpar ^ 1;
-    GeomSet &S = c->gset[par];
+    // Beside the previous pass's tile kernel (second stream, the other workspace set) or after it (the targets' stream,
+    // set 0: one set stays hot in the 256 MB Infinity Cache -- two sets of the 1M-triangle frame do not, which costs its
+    // tile kernel 4 us).  Measured (profiles/r03_overlap_modes.txt): running beside pays for passes with varyings, whose
+    // tile kernel spends long stretches shading (4K textured frame -6 %, a rank of 8 of it -10 %), not for depth-only ones.
+    const bool on_g = c->overlap == 1 || (c->overlap == 2 && K > 0);
+    const int si = on_g ? (f.gset ^ 1) : 0;
+    GeomSet &S = c->gset[si];
     int rc;
     const UserModule *um = nullptr;
     if (m.vs >= FRR_SHADER_USER_BASE && (rc = user_module(c, m.vs, &um)) != FRR_OK) return rc;
@@ -562,6 +581,14 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
     const bool use_clipq = nt > 0 && (c->clip_queue > 0 || (c->clip_queue < 0 && c->clip_queue_auto));
     if (use_clipq && (rc = ensure(c, S.clipq, S.clipq_cap, (size_t)nt)) != FRR_OK) return rc;
     if ((rc = scan_now(c)) != FRR_OK) return rc;   // the previous pass's n_emit feeds this pass's tri_base
+    if (on_g != f.on_g) {
+        // this pass changes streams: it follows the previous pass's geometry + binning (tri_base, fan cursors)
+        hipEvent_t e = c->ev_bin[++c->bin_serial & 3];
+        HIP_TRY(c, hipEventRecord(e, gstream_of(c)));
+        HIP_TRY(c, hipStreamWaitEvent(on_g ? c->gstream : tstream_of(c), e, 0));
+    }
+    f.on_g = on_g;
+    if (on_g) c->g_used = true;
     // second stream: after whatever the caller's stream holds that this pass may read (first use), and after the tile
     // kernel that last read this workspace
     if ((rc = gstream_join(c)) != FRR_OK) return rc;
@@ -584,7 +611,7 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
     g.bcount = S.bcount;
     // what the setup list about to be built was filtered by (frr_raster / frr_readback_setup check it)
     f.geom_filter = GeomFilter{cmd.filter, cmd.fy0, cmd.fy1, f.rank, f.world, f.part_blocked};
-    f.gpar = par; cmd.par = par;
+    f.gpar = par; cmd.par = par; f.gset = si;
     f.geom_fan_cap = (uint32_t)fan_cap;
     f.geom_nblocks = nblocks;
     f.geom_seq = cmd.seq;
@@ -615,7 +642,7 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
         if (full && !c->raster_sweep) fuse = true; // the tile kernel performs the clear
         else { int rcs = settle_targets(c); if (rcs != FRR_OK) return rcs; }
     }
-    GeomSet &S = c->gset[f.gpar];
+    GeomSet &S = c->gset[f.gset];
     RasterArgs a;
     a.fused_clear = fuse ? 1 : 0; a.clear_rgba = f.clear_rgba; a.clear_depth = f.clear_depth;
     a.x0 = x0; a.x1 = x1; a.y0 = y0; a.y1 = y1; a.win_w = (int)ww; a.win_h = (int)wh;
@@ -644,12 +671,13 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
     const SpanShape sh = span_shape(c, grid, f.geom_ntris, ps_id);
     const bool segmented = grid <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep;
     const int q = segmented ? (f.bpar ^ 1) : 0;   // (the CSR fallback has one set of tile tables: it uses workspace 0 and overlaps nothing)
-    BinSet &B = c->bset[q];
+    const int bi = (segmented && f.on_g) ? (f.bset ^ 1) : 0;
+    BinSet &B = c->bset[bi];
     int rc;
     if (!B.bins) {
         size_t want = std::max<size_t>((size_t)f.geom_ntris * 8 + 4 * (size_t)c->max_tiles, (size_t)1 << 22);
         if (c->bin_cap_init) want = c->bin_cap_init;      // option bin_capacity (tests of the replay)
-        want = std::max(want, c->bset[q ^ 1].bin_cap);   // (what the other workspace has grown to)
+        want = std::max(want, c->bset[bi ^ 1].bin_cap);   // (what the other workspace has grown to)
         if ((rc = ensure(c, B.bins, B.bin_cap, want)) != FRR_OK) return rc;
         if ((rc = ensure(c, B.bins2, B.bin2_cap, want)) != FRR_OK) return rc;
     }
@@ -693,7 +721,7 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
                                f.geom_fan_cap, S.block_sums, S.block_prefix, f.geom_nblocks, do_scan);
         }
         f.scan_pending = false;
-        f.bpar = q;
+        f.bpar = q; f.bset = bi;
     } else {
         // fallback for frames with more tiles than fit LDS counters: global atomics (one set of tile tables: after every
         // tile kernel so far)
@@ -705,7 +733,7 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
         { ProfScope p(c, KID_TILE_SCAN, gs); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, gs, a, ntiles); }
         { ProfScope p(c, KID_BIN_FILL, gs); hipLaunchKernelGGL(k_bin<true>, dim3(bin_grid), dim3(256), 0, gs, a, f.geom_fan_cap); }
     }
-    cmd.par = q;
+    cmd.par = q; cmd.set = bi;
     HIP_TRY(c, hipGetLastError());
     if ((rc = tstream_wait_gstream(c)) != FRR_OK) return rc;   // the tile kernel runs on the targets' stream, after the binning
     if (grid && um) {
@@ -776,7 +804,7 @@ int finish(frr_ctx *c)
             const uint64_t worst = std::max<uint64_t>(h.bin_total, std::max<uint64_t>(h.btab[0].seg_total, h.btab[1].seg_total));
             const size_t need = (size_t)(worst + worst / 4 + 1024);
             for (BinSet &B : c->bset) {
-                if (!B.bins && &B != &c->bset[c->log[i].par]) continue;   // (a workspace nobody has used yet is sized when it is)
+                if (!B.bins && &B != &c->bset[c->log[i].set]) continue;   // (a workspace nobody has used yet is sized when it is)
                 if ((rc = ensure(c, B.bins, B.bin_cap, std::max(need, B.bin_cap))) != FRR_OK) return rc;
                 if ((rc = ensure(c, B.bins2, B.bin2_cap, std::max(need, B.bin2_cap))) != FRR_OK) return rc;
             }
@@ -968,7 +996,7 @@ int frr_set_option(frr_ctx *c, const char *name, int64_t v)
     else if (n == "bin_atomics") c->bin_atomics = v != 0;
     else if (n == "bin_capacity") { if (v < 0) return fail(c, FRR_ERR_INVALID, "bin_capacity >= 0"); c->bin_cap_init = (size_t)v; }
     else if (n == "fan_capacity") { if (v < 0) return fail(c, FRR_ERR_INVALID, "fan_capacity >= 0"); c->fan_cap_init = (size_t)v; }
-    else if (n == "overlap") { c->overlap = v != 0; c->need_join = true; }
+    else if (n == "overlap") { if (v < 0 || v > 2) return fail(c, FRR_ERR_INVALID, "overlap: 0, 1 or 2"); c->overlap = (int)v; c->need_join = true; }
     else if (n == "frames_in_flight") { if (v != 1 && v != 2) return fail(c, FRR_ERR_INVALID, "frames_in_flight: 1 or 2"); c->frames_in_flight = (int)v; }
     else return fail(c, FRR_ERR_INVALID, "unknown option");
     return FRR_OK;
@@ -1322,7 +1350,7 @@ int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uin
     { int rcs = finish(c); if (rcs != FRR_OK) return rcs; }
     const FrameState &f = c->fs;
     const GeomTab &gt = c->hc.gtab[f.gpar];
-    const GeomSet &S = c->gset[f.gpar];
+    const GeomSet &S = c->gset[f.gset];
     const uint64_t nt = f.geom_ntris;
     *ntris = nt ? gt.n_emit : 0;
     if (!out || !nt) return FRR_OK;
@@ -1403,7 +1431,7 @@ int frr_event_record(frr_ctx *c, int slot)
 {
     if (!c || slot < 0 || slot >= 16) return FRR_ERR_INVALID;
     // (a measuring call: the caller's stream first waits for the ctx's other streams, so that the event brackets whole frames)
-    if (c->overlap) { HIP_TRY(c, hipEventRecord(c->ev_join, c->gstream)); HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
+    if (c->g_used) { HIP_TRY(c, hipEventRecord(c->ev_join, c->gstream)); HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
     { int rcj = join_tile_streams(c); if (rcj != FRR_OK) return rcj; }
     HIP_TRY(c, hipEventRecord(c->ev[slot], c->stream));
     c->ev_set[slot] = true;

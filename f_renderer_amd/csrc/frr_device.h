@@ -89,10 +89,19 @@ struct Counters {
 };
 
 // has a command with sequence number `seq` been cancelled by an earlier failure?  (`own`: also by its own)
+// The hot kernels read the number first thing (seq_first_bad) and test it where they wait for their first loads anyway
+// (seq_is_cancelled): a test right at the top would put one more memory round trip in front of every workgroup.
+__device__ __forceinline__ uint32_t seq_first_bad(const Counters *cnt)
+{
+    return __hip_atomic_load(&cnt->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool seq_is_cancelled(uint32_t b, uint32_t seq, uint32_t epoch, bool own)
+{
+    return b >= epoch && (own ? b <= seq : b < seq);
+}
 __device__ __forceinline__ bool seq_cancelled(const Counters *cnt, uint32_t seq, uint32_t epoch, bool own)
 {
-    const uint32_t b = __hip_atomic_load(&cnt->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return b >= epoch && (own ? b <= seq : b < seq);
+    return seq_is_cancelled(seq_first_bad(cnt), seq, epoch, own);
 }
 // a work list of command `seq` is too small (bits: which)
 __device__ __forceinline__ void seq_fail(Counters *cnt, uint32_t seq, uint32_t epoch, uint32_t bits)

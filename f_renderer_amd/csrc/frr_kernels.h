@@ -531,9 +531,8 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K;
     const uint32_t bid = blockIdx.x;
     const uint32_t t = bid * GEOM_BLOCK + threadIdx.x;
-    if (seq_cancelled(g.cnt, g.seq, g.epoch, false)) return;   // an earlier command failed: the host replays from there
+    const uint32_t first_bad = seq_first_bad(g.cnt);   // (tested below, where the vertex loads are waited for anyway)
     GeomTab *const gt = &g.cnt->gtab[g.gpar];
-    if (bid == 0 && threadIdx.x == 0) geom_bookkeeping(g);
     if (threadIdx.x == 0) s_ncl = 0; // ordered before its use by the barriers inside block_excl_scan256
     float pos[3][4];
     float ctx[3][K > 0 ? K : 1];
@@ -545,6 +544,8 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
         for (int v = 0; v < 3; ++v) run_vs<VS, true>(u, in + v * NF, pos[v], ctx[v]);
         n = classify(pos, clipped);
     }
+    if (seq_is_cancelled(first_bad, g.seq, g.epoch, false)) return;   // an earlier command failed: the host replays from there (nothing written yet)
+    if (bid == 0 && threadIdx.x == 0) geom_bookkeeping(g);
     // Multi-GPU: a clipped input is expanded (and gets fan slots) only where its fan can reach a tile row of this rank.
     // The fan's vertices are the three originals and intersections a + r(b - a); with all w > 0 and no vertex beyond the
     // near plane (whose ratio is the reference's a_w / (a_w - b_w), not a point of the edge: renderer.rs:70) every r is in
@@ -862,16 +863,18 @@ __global__ __launch_bounds__(1024) void k_tile_scan(RasterArgs a, uint32_t ntile
 __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntiles, uint32_t *__restrict__ seg,
                                                     uint32_t stage_cap, uint32_t fan_cap, const uint32_t *block_sums, uint32_t *block_prefix, uint32_t nblocks, int do_scan)
 {
-    if (seq_cancelled(a.cnt, a.seq, a.epoch, false)) return;
-    // do_scan: the launch's LAST workgroup scans the geometry kernel's block sums instead (the tile kernel's resolve
-    // needs the prefix for triangle ids; here it costs no launch and sits on nobody's critical path)
-    if (do_scan && blockIdx.x == gridDim.x - 1) { geom_scan(block_sums, block_prefix, nblocks, a.cnt, a.gpar, fan_cap, a.geom_seq, a.epoch); return; }
+    const uint32_t first_bad = seq_first_bad(a.cnt);   // (tested once the histogram is zeroed: nothing is written before)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[]; // [ntiles], then the staging records
     uint4 *s_stage = reinterpret_cast<uint4 *>(s_hist + ((ntiles + 3u) & ~3u));
     __shared__ uint32_t s_w[2][BIN_WG / 64];
     __shared__ uint32_t s_base;
     const uint32_t g = blockIdx.x, G = gridDim.x - (uint32_t)do_scan;
-    for (uint32_t t = threadIdx.x; t < ((ntiles + 3u) & ~3u); t += BIN_WG) s_hist[t] = 0u;   // (padded to four: bin_scan_relative)
+    const bool scan_wg = do_scan && blockIdx.x == gridDim.x - 1;
+    if (!scan_wg) for (uint32_t t = threadIdx.x; t < ((ntiles + 3u) & ~3u); t += BIN_WG) s_hist[t] = 0u;   // (padded to four: bin_scan_relative)
+    if (seq_is_cancelled(first_bad, a.seq, a.epoch, false)) return;
+    // do_scan: the launch's LAST workgroup scans the geometry kernel's block sums instead (the tile kernel's resolve
+    // needs the prefix for triangle ids; here it costs no launch and sits on nobody's critical path)
+    if (scan_wg) { geom_scan(block_sums, block_prefix, nblocks, a.cnt, a.gpar, fan_cap, a.geom_seq, a.epoch); return; }
     if (g == 0 && threadIdx.x == 0) bin_bookkeeping(a.cnt, a.bpar, a.frame_no);
     __syncthreads();
     // a workgroup's chunk: a range of geometry blocks (their dense entries) and a range of the used fan entries

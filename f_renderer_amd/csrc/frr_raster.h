@@ -582,9 +582,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
 #else
 #define FRR_T(i) do { } while (0)
 #endif
-    if (seq_cancelled(a.cnt, a.seq, a.epoch, true)) return; // this or an earlier command failed: the targets stay as they are, the host replays
+    const uint32_t first_bad = seq_first_bad(a.cnt);   // (tested below, where the first loads are waited for anyway)
     TileCtx c = tile_ctx(a);
     const bool segmented = a.nseg != 0;
+    if (!segmented && seq_is_cancelled(first_bad, a.seq, a.epoch, true)) return;
     if (segmented) {
         // column c.ltile of the segment table: (start, end) of this tile's records in each chunk's region
         uint32_t s0 = 0, cn = 0;
@@ -593,6 +594,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             s0 = r[0];
             cn = r[1] - s0;
         }
+        // this or an earlier command failed: the targets stay as they are, the host replays (frr_device.h: Counters::first_bad)
+        if (seq_is_cancelled(first_bad, a.seq, a.epoch, true)) return;
         const uint32_t inc = wave_incl_scan_dpp(cn);
         if (lane == 63 && w < 4) s_w4[w] = inc;
         // three waves: segments 192..255 are a second column read of wave 0 (the host keeps nseg <= 256 then, else <= NW * 64)

@@ -291,6 +291,15 @@ public:
     void free_mesh(Mesh &m) { if (m.id >= 0) { check(frr_mesh_free(ctx_, m.id)); m.id = -1; } }
     void set_texture(int slot, const FrameBuffer &fb) { check(frr_texture_upload(ctx_, slot, fb.get_data().data(), fb.width(), fb.height())); }
     void set_uniforms() { check(frr_set_uniforms(ctx_, &uniforms)); }
+    // The reference's closure shaders (renderer.rs:105,283) as HIP text compiled at run time (include/frr.h: user shaders):
+    // returns the id to upload a mesh with (vs_id) and to draw it with (pixel_shader).
+    int register_shader(const std::string &hip_source, int vs_input_floats, int num_varyings)
+    {
+        int id = -1;
+        check(frr_shader_register(ctx_, hip_source.c_str(), vs_input_floats, num_varyings, &id));
+        return id;
+    }
+    void set_user_uniforms(const std::vector<float> &v) { check(frr_set_user_uniforms(ctx_, v.data(), (int)v.size())); }   // what the closures would capture
     void set_option(const char *name, int64_t value) { check(frr_set_option(ctx_, name, value)); }   // dev / test switches, include/frr.h
     void set_partition(int rank, int world, bool blocked = false)
     {

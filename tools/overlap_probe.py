@@ -8,9 +8,14 @@ from f_renderer_amd import scenes
 cfg = scenes.build_config(os.environ.get("CFG", "headline"))
 W, H = cfg["W"], cfg["H"]
 N = int(os.environ.get("N", "200"))
-for overlap in ([int(os.environ["OVERLAP"])] if os.environ.get("OVERLAP") else [0, 1, 0, 1]):
+modes = [(int(os.environ["OVERLAP"]), int(os.environ.get("FIF", "2")))] if os.environ.get("OVERLAP") else [(0, 1), (1, 1), (2, 1)]
+for overlap, fif in modes:
     r = fr.Renderer(W, H)
     r.set_option("overlap", overlap)
+    r.set_option("frames_in_flight", fif)
+    if os.environ.get("PART"):
+        rk, wd = (int(x) for x in os.environ["PART"].split(","))
+        r.set_partition(rk, wd, blocked=True)
     if cfg["tex"] is not None:
         r.set_texture(0, cfg["tex"])
         eye, at, up, fovy, aspect, zn, zf = scenes.demo_camera(W, H)
@@ -27,5 +32,5 @@ for overlap in ([int(os.environ["OVERLAP"])] if os.environ.get("OVERLAP") else [
     t1 = time.perf_counter()
     r.sync()
     t2 = time.perf_counter()
-    print(f"overlap={overlap}: host enqueue {(t1 - t0) / N * 1e6:.1f} us/frame, frame {(t2 - t0) / N * 1e6:.1f} us, replays {r.stats()['replays']}", flush=True)
+    print(f"{os.environ.get('CFG', 'headline')} part={os.environ.get('PART', '-')} overlap={overlap} frames_in_flight={fif}: host enqueue {(t1 - t0) / N * 1e6:.1f} us/frame, frame {(t2 - t0) / N * 1e6:.1f} us, replays {r.stats()['replays']}", flush=True)
     r.close()
