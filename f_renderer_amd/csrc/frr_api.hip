@@ -113,7 +113,10 @@ struct FrameState {
     uint32_t clear_rgba = 0; float clear_depth = 0.0f;
     uint32_t frame_no = 1;         // frr_clear count (device statistics are tagged with it)
     uint64_t tris_in = 0; uint32_t draws = 0;   // statistics the host knows: inputs submitted / geometry passes since frr_clear
-    int gpar = 0, bpar = 0;        // parity of the latest geometry / raster pass (device tables GeomTab / BinTab)
+    int lane = 0;                  // which of the two sets of device tables this frame's passes use (frr_device.h: Lane)
+    int gpars[2] = {0, 0}, bpars[2] = {0, 0};   // per lane: parity of the latest geometry / raster pass (GeomTab / BinTab)
+    int gpar() const { return gpars[lane]; }
+    int bpar() const { return bpars[lane]; }
     int gset = 0, bset = 0;        // workspace set of the latest geometry / raster pass (GeomSet / BinSet)
     bool on_g = false;             // the latest geometry pass runs on the second stream (its binning follows it there)
     GeomFilter geom_filter = {false, 0, 0, 0, 1, false}; // tile-row ownership filter the latest setup list was built with (frr_draw on a partitioned ctx)
@@ -136,6 +139,7 @@ struct Cmd {
     int ps = 0; int32_t x0 = 0, x1 = 0, y0 = 0, y1 = 0; bool count_frags = true;
     int par = 0;               // the parity it ran with (finish(): which table a failed command left behind)
     int set = 0;               // RASTER: the BinSet it ran with
+    int lane = 0;              // the lane of device tables it ran in
 };
 
 } // namespace
@@ -157,7 +161,7 @@ struct frr_ctx {
     hipStream_t tstream2 = nullptr;  // tile kernels / clears of own target set 1
     hipEvent_t ev_t2 = nullptr;      // joins tstream2 into `stream`
     bool t2_dirty = false;           // tstream2 holds work `stream` has not waited for
-    int frames_in_flight = 1;        // option frames_in_flight (1: one set, one tile stream; 2 was measured slower on every workload, profiles/r03_overlap_modes.txt)
+    int frames_in_flight = 2;        // option frames_in_flight (1: one target set, everything on the caller's stream)
     Counters *cnt = nullptr;
     FrameState fs;
     GeomSet gset[2];
@@ -437,7 +441,7 @@ int scan_now(frr_ctx *c)
     FrameState &f = c->fs;
     if (!f.scan_pending) return FRR_OK;
     hipStream_t st = gstream_of(c);
-    { ProfScope p(c, KID_GEOM_SCAN, st); hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, st, c->gset[f.gset].block_sums, c->gset[f.gset].block_prefix, f.geom_nblocks, c->cnt, f.gpar, f.geom_fan_cap, f.geom_seq, c->epoch); }
+    { ProfScope p(c, KID_GEOM_SCAN, st); hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, st, c->gset[f.gset].block_sums, c->gset[f.gset].block_prefix, f.geom_nblocks, c->cnt, f.lane, f.gpar(), f.geom_fan_cap, f.geom_seq, c->epoch); }
     HIP_TRY(c, hipGetLastError());
     f.scan_pending = false;
     return FRR_OK;
@@ -544,13 +548,14 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
     const Mesh &m = c->meshes[cmd.mesh];
     const int K = frr_vs_num_varyings(m.vs);
     const uint64_t nt = m.ntris;
-    const int par = f.gpar ^ 1;
+    const int par = f.gpar() ^ 1;
     // Beside the previous pass's tile kernel (second stream, the other workspace set) or after it (the targets' stream,
     // set 0: one set stays hot in the 256 MB Infinity Cache -- two sets of the 1M-triangle frame do not, which costs its
     // tile kernel 4 us).  Measured (profiles/r03_overlap_modes.txt): running beside pays for passes with varyings, whose
     // tile kernel spends long stretches shading (4K textured frame -6 %, a rank of 8 of it -10 %), not for depth-only ones.
-    const bool on_g = c->overlap == 1 || (c->overlap == 2 && K > 0);
-    const int si = on_g ? (f.gset ^ 1) : 0;
+    const bool fif2 = c->frames_in_flight == 2 && own_targets(c);   // consecutive frames already run beside each other, on two streams (frr_clear)
+    const bool on_g = !fif2 && (c->overlap == 1 || (c->overlap == 2 && K > 0));
+    const int si = on_g ? (f.gset ^ 1) : (fif2 ? f.tset : 0);
     GeomSet &S = c->gset[si];
     int rc;
     const UserModule *um = nullptr;
@@ -604,14 +609,14 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
         g.part_blocked = 1;
         blocked_rows(tiles_y, f.rank, f.world, &g.part_brow0, &g.part_brow1);
     }
-    g.gpar = par;
+    g.gpar = par; g.lane = f.lane;
     g.block_sums = S.block_sums; g.block_prefix = S.block_prefix; g.tinfo = S.tinfo; g.fanbase = S.fanbase; g.fan_okey = S.fan_okey;
     g.recs = S.recs; g.vary = S.vary; g.pbox = S.pbox; g.cnt = c->cnt;
     g.clipq = S.clipq; g.use_clipq = use_clipq ? 1 : 0;
     g.bcount = S.bcount;
     // what the setup list about to be built was filtered by (frr_raster / frr_readback_setup check it)
     f.geom_filter = GeomFilter{cmd.filter, cmd.fy0, cmd.fy1, f.rank, f.world, f.part_blocked};
-    f.gpar = par; cmd.par = par; f.gset = si;
+    f.gpars[f.lane] = par; cmd.par = par; cmd.lane = f.lane; f.gset = si;
     f.geom_fan_cap = (uint32_t)fan_cap;
     f.geom_nblocks = nblocks;
     f.geom_seq = cmd.seq;
@@ -654,7 +659,7 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
     if (a.blocked) blocked_rows(a.tiles_y, a.rank, a.world, &a.brow0, &a.brow1);
     a.recs = S.recs; a.vary = S.vary; a.pbox = S.pbox; a.bcount = S.bcount;
     a.tile_counts = c->tile_counts; a.tile_offsets = c->tile_offsets; a.tile_cursor = c->tile_cursor;
-    a.gpar = f.gpar; a.bpar = 0; a.seq = cmd.seq; a.epoch = c->epoch; a.frame_no = f.frame_no; a.geom_seq = f.geom_seq;
+    a.gpar = f.gpar(); a.lane = f.lane; a.bpar = 0; a.seq = cmd.seq; a.epoch = c->epoch; a.frame_no = f.frame_no; a.geom_seq = f.geom_seq;
     const uint32_t ntiles = (uint32_t)a.tiles_x * a.tiles_y;
     a.color = f.color; a.depth = f.depth; a.tri_id = f.tri_id; a.cnt = c->cnt;
 #ifdef FRR_DEBUG_COUNTERS
@@ -670,8 +675,8 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
     if (a.tiles_x >= 2 && a.tiles_x < 65536 && grid < 65536u) a.tiles_x_magic = (uint32_t)(0x100000000ull / (uint64_t)a.tiles_x + 1ull);
     const SpanShape sh = span_shape(c, grid, f.geom_ntris, ps_id);
     const bool segmented = grid <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep;
-    const int q = segmented ? (f.bpar ^ 1) : 0;   // (the CSR fallback has one set of tile tables: it uses workspace 0 and overlaps nothing)
-    const int bi = (segmented && f.on_g) ? (f.bset ^ 1) : 0;
+    const int q = segmented ? (f.bpar() ^ 1) : 0;   // (the CSR fallback has one set of tile tables: it uses workspace 0 and overlaps nothing)
+    const int bi = !segmented ? 0 : f.on_g ? (f.bset ^ 1) : ((c->frames_in_flight == 2 && own_targets(c)) ? f.tset : 0);
     BinSet &B = c->bset[bi];
     int rc;
     if (!B.bins) {
@@ -721,7 +726,7 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
                                f.geom_fan_cap, S.block_sums, S.block_prefix, f.geom_nblocks, do_scan);
         }
         f.scan_pending = false;
-        f.bpar = q; f.bset = bi;
+        f.bpars[f.lane] = q; f.bset = bi;
     } else {
         // fallback for frames with more tiles than fit LDS counters: global atomics (one set of tile tables: after every
         // tile kernel so far)
@@ -733,7 +738,7 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
         { ProfScope p(c, KID_TILE_SCAN, gs); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, gs, a, ntiles); }
         { ProfScope p(c, KID_BIN_FILL, gs); hipLaunchKernelGGL(k_bin<true>, dim3(bin_grid), dim3(256), 0, gs, a, f.geom_fan_cap); }
     }
-    cmd.par = q; cmd.set = bi;
+    cmd.par = q; cmd.set = bi; cmd.lane = f.lane;
     HIP_TRY(c, hipGetLastError());
     if ((rc = tstream_wait_gstream(c)) != FRR_OK) return rc;   // the tile kernel runs on the targets' stream, after the binning
     if (grid && um) {
@@ -792,7 +797,13 @@ int finish(frr_ctx *c)
         if ((rc = drain(c)) != FRR_OK) return rc;
         HIP_TRY(c, hipMemcpy(&c->hc, c->cnt, sizeof(Counters), hipMemcpyDeviceToHost));
         Counters &h = c->hc;
-        c->clip_queue_auto = std::max(h.gtab[0].clip_block_max, h.gtab[1].clip_block_max) > (uint32_t)CLIP_QUEUE_AT;
+        uint32_t cbm = 0, need_fans = 0; uint64_t worst_bins = 0;
+        for (const Lane &L : h.lane) {
+            cbm = std::max(cbm, std::max(L.gtab[0].clip_block_max, L.gtab[1].clip_block_max));
+            need_fans = std::max(need_fans, std::max(L.gtab[0].need_fans, L.gtab[1].need_fans));
+            worst_bins = std::max<uint64_t>(worst_bins, std::max<uint64_t>(L.bin_total, std::max<uint64_t>(L.btab[0].seg_total, L.btab[1].seg_total)));
+        }
+        c->clip_queue_auto = cbm > (uint32_t)CLIP_QUEUE_AT;
         const uint32_t bad = h.first_bad;
         if (bad == SEQ_NONE || bad < c->epoch) break;
         size_t i = 0;
@@ -801,7 +812,7 @@ int finish(frr_ctx *c)
         if (round == 8) return fail(c, FRR_ERR_CAPACITY, "device work lists still too small after eight replays");
         // grow what was too small
         if (h.overflow & 2u) {
-            const uint64_t worst = std::max<uint64_t>(h.bin_total, std::max<uint64_t>(h.btab[0].seg_total, h.btab[1].seg_total));
+            const uint64_t worst = worst_bins;
             const size_t need = (size_t)(worst + worst / 4 + 1024);
             for (BinSet &B : c->bset) {
                 if (!B.bins && &B != &c->bset[c->log[i].set]) continue;   // (a workspace nobody has used yet is sized when it is)
@@ -810,7 +821,7 @@ int finish(frr_ctx *c)
             }
         }
         if (h.overflow & 1u) {
-            const uint64_t nf = std::max(h.gtab[0].need_fans, h.gtab[1].need_fans);
+            const uint64_t nf = need_fans;
             c->fan_hint = std::max<size_t>(c->fan_hint, (size_t)(nf + nf / 8 + 1024));
         }
         // the device tables as they were before the failed command: it has used its own parity's cursors (and, when its
@@ -819,11 +830,11 @@ int finish(frr_ctx *c)
         for (size_t k = i; k < std::min(i + 2, c->log.size()); ++k) {
             const Cmd &m = c->log[k];
             if (m.kind == Cmd::GEOM && k == i) {
-                GeomTab &gt = h.gtab[m.par];
+                GeomTab &gt = h.lane[m.lane].gtab[m.par];
                 for (int r = 0; r < FAN_REGIONS; ++r) gt.fan_cursor[r].v = 0u;
                 gt.clip_q = 0u; gt.clip_block_max = 0u; gt.n_emit = 0u; gt.need_fans = 0u;
             } else if (m.kind == Cmd::RASTER) {
-                h.btab[m.par].seg_total = 0ull; h.btab[m.par].ent_cursor = 0u;
+                h.lane[m.lane].btab[m.par].seg_total = 0ull; h.lane[m.lane].btab[m.par].ent_cursor = 0u;
             }
         }
         HIP_TRY(c, hipMemcpy(c->cnt, &h, offsetof(Counters, dbg), hipMemcpyHostToDevice));
@@ -1245,6 +1256,9 @@ int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
         }
         f.tset = t;
         f.color = c->own_color[t]; f.depth = c->own_depth[t]; f.tri_id = c->own_tri_id[t];
+        f.lane = t;    // ... and its own device tables: nothing the two frames' bookkeeping threads write is shared
+    } else {
+        f.lane = 0;
     }
     if (c->clear_eager) { f.clear_pending = false; return clear_now(c, packed, depth); }
     f.clear_rgba = packed; f.clear_depth = depth;
@@ -1262,7 +1276,7 @@ int frr_geometry(frr_ctx *c, int mesh, uint64_t *ntris_setup)
     if (rc != FRR_OK) return rc;
     if (ntris_setup) {
         if ((rc = finish(c)) != FRR_OK) return rc;
-        *ntris_setup = c->hc.gtab[c->fs.gpar].n_emit;
+        *ntris_setup = c->hc.lane[c->fs.lane].gtab[c->fs.gpar()].n_emit;
     }
     return FRR_OK;
 }
@@ -1349,7 +1363,7 @@ int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uin
         return fail(c, FRR_ERR_INVALID, "the setup list of a partitioned frr_draw holds only this rank's triangles; use frr_geometry to read back the full Vec<[Vertex;3]>");
     { int rcs = finish(c); if (rcs != FRR_OK) return rcs; }
     const FrameState &f = c->fs;
-    const GeomTab &gt = c->hc.gtab[f.gpar];
+    const GeomTab &gt = c->hc.lane[f.lane].gtab[f.gpar()];
     const GeomSet &S = c->gset[f.gset];
     const uint64_t nt = f.geom_ntris;
     *ntris = nt ? gt.n_emit : 0;
@@ -1399,7 +1413,7 @@ int frr_get_stats(frr_ctx *c, frr_stats *out)
     if (!c || !out) return FRR_ERR_INVALID;
     { int rc = finish(c); if (rc != FRR_OK) return rc; }
     const FrameState &f = c->fs;
-    const Counters &h = c->hc;
+    const Lane &h = c->hc.lane[f.lane];
     const bool tot = h.totals_frame == f.frame_no;
     memset(out, 0, sizeof *out);
     out->tris_in = f.tris_in;
@@ -1412,13 +1426,13 @@ int frr_get_stats(frr_ctx *c, frr_stats *out)
         if (h.gtab[p].frame_no == f.frame_no) { out->frag_covered += h.gtab[p].frag_covered; out->frag_nan += h.gtab[p].frag_nan; }
         if (h.btab[p].frame_no == f.frame_no) out->bin_entries += h.btab[p].seg_total;
     }
-    if (f.draws && h.gtab[f.gpar].frame_no == f.frame_no) out->tris_setup = (uint64_t)h.gtab[f.gpar].tri_base + h.gtab[f.gpar].n_emit;
+    if (f.draws && h.gtab[f.gpar()].frame_no == f.frame_no) out->tris_setup = (uint64_t)h.gtab[f.gpar()].tri_base + h.gtab[f.gpar()].n_emit;
 #ifdef FRR_DEBUG_COUNTERS
     if (getenv("FRR_DEBUG_PRINT")) {
         fprintf(stderr, "frr dbg:");
         for (int k = 0; k < 24; ++k) {
             unsigned long long v = 0;
-            for (int j = 0; j < DBG_COPIES; ++j) v += h.dbg[j][k];
+            for (int j = 0; j < DBG_COPIES; ++j) v += c->hc.dbg[j][k];
             fprintf(stderr, " %llu", v);
         }
         fprintf(stderr, "\n");

@@ -73,15 +73,22 @@ struct BinTab {
 // grows the list and replays the commands from there (frr_api.hip: finish) -- the caller never sees the overflow.
 constexpr uint32_t SEQ_NONE = 0xFFFFFFFFu;
 
-struct Counters {
-    uint32_t first_bad;     // see above
-    uint32_t overflow;      // bit0 fan capacity, bit1 bin capacity (which list to grow)
+// A LANE is the set of tables one frame's passes alternate between.  A ctx that keeps two frames in flight (own targets:
+// consecutive frames run on two streams, frr_api.hip) gives each its own lane, so that the bookkeeping threads of two
+// frames never touch the same words; within a lane the geometry + binning kernels of consecutive passes never overlap.
+struct alignas(128) Lane {
     uint32_t totals_frame;  // the frame the totals below belong to
     uint32_t pad0;
     unsigned long long tot_frag_covered, tot_frag_nan, tot_bin_entries; // of the passes whose tables have been recycled
     unsigned long long bin_total;     // (triangle,tile) pairs of the latest CSR binning
     BinTab btab[2];
     GeomTab gtab[2];
+};
+struct Counters {
+    uint32_t first_bad;     // see above
+    uint32_t overflow;      // bit0 fan capacity, bit1 bin capacity (which list to grow)
+    uint32_t pad0[2];
+    Lane lane[2];
     // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py): funnel counters and per-phase wave cycles of the tile
     // kernel, in DBG_COPIES copies (workgroup b adds to copy b % DBG_COPIES: thousands of device atomics on one cache
     // line would serialise at ~17 ns each and distort what they measure); the host adds the copies up
@@ -148,6 +155,7 @@ struct GeomArgs {
     uint32_t fan_cap;       // capacity of the fan space (triangles): FAN_REGIONS regions of fan_cap / FAN_REGIONS (a multiple of FAN_REGIONS)
     uint32_t seq, epoch;    // sequence number of this geometry pass / failures before `epoch` are stale (Counters::first_bad)
     uint32_t frame_no;      // frr_clear count: statistics are folded per frame (GeomTab::frame_no)
+    int32_t lane;           // which Counters::lane this pass's tables live in
     int32_t part_rank, part_world; // tile-row ownership filter (world == 1: none); only set by frr_draw,
     int32_t part_y0, part_y1;      // which knows the raster window's height range
     int32_t part_blocked, part_brow0, part_brow1; // blocked partition: the rank owns tile rows [brow0, brow1) (RasterArgs)
@@ -189,6 +197,7 @@ struct RasterArgs {
     int32_t bpar;                     // parity of this raster pass: which Counters::btab it uses
     int32_t gpar;                     // parity of the geometry pass it rasterizes: which Counters::gtab it reads
     uint32_t seq, epoch, frame_no;    // this raster pass's sequence number etc. (Counters::first_bad, GeomTab::frame_no)
+    int32_t lane;                     // which Counters::lane both tables live in
     uint32_t geom_seq;                // the geometry pass's number (its block-sum scan may ride in this pass's binning launch)
     int32_t fused_clear;              // this draw also performs the pending frr_clear for the tiles it owns:
     uint32_t clear_rgba;              //   keys start from clear_depth instead of the depth buffer and every pixel
@@ -254,11 +263,11 @@ __device__ __forceinline__ uint32_t fan_map_slot(const FanMap &m, uint32_t v)
 
 // Frame statistics are kept per pass (GeomTab / BinTab) and folded into the totals when a table is recycled; a table
 // or a total of an older frame (frr_clear count) is simply dropped -- frr_clear itself touches nothing on the device.
-__device__ __forceinline__ void totals_for_frame(Counters *cnt, uint32_t frame_no)
+__device__ __forceinline__ void totals_for_frame(Counters *cnt, Lane &L, uint32_t frame_no)
 {
-    if (cnt->totals_frame != frame_no) {
-        cnt->totals_frame = frame_no;
-        cnt->tot_frag_covered = 0ull; cnt->tot_frag_nan = 0ull; cnt->tot_bin_entries = 0ull;
+    if (L.totals_frame != frame_no) {
+        L.totals_frame = frame_no;
+        L.tot_frag_covered = 0ull; L.tot_frag_nan = 0ull; L.tot_bin_entries = 0ull;
         for (int j = 0; j < DBG_COPIES; ++j) for (int k = 0; k < 24; ++k) cnt->dbg[j][k] = 0;
     }
 }
@@ -266,15 +275,16 @@ __device__ __forceinline__ void totals_for_frame(Counters *cnt, uint32_t frame_n
 // the binning launch's bookkeeping (one thread).  The OTHER table belongs to the previous raster pass, whose binning has
 // drained (same stream): its total is folded and zeroed for the pass after this one.  (Its ent_cursor may still be in use
 // by that pass's tile kernel on the other stream: every pass zeroes its OWN before its tile kernel starts.)
-__device__ __forceinline__ void bin_bookkeeping(Counters *cnt, int bpar, uint32_t frame_no)
+__device__ __forceinline__ void bin_bookkeeping(Counters *cnt, int lane, int bpar, uint32_t frame_no)
 {
-    totals_for_frame(cnt, frame_no);
-    BinTab &o = cnt->btab[bpar ^ 1];
-    if (o.frame_no == frame_no) cnt->tot_bin_entries += o.seg_total;
+    Lane &L = cnt->lane[lane];
+    totals_for_frame(cnt, L, frame_no);
+    BinTab &o = L.btab[bpar ^ 1];
+    if (o.frame_no == frame_no) L.tot_bin_entries += o.seg_total;
     o.seg_total = 0ull;
     o.frame_no = SEQ_NONE;
-    cnt->btab[bpar].ent_cursor = 0u;
-    cnt->btab[bpar].frame_no = frame_no;
+    L.btab[bpar].ent_cursor = 0u;
+    L.btab[bpar].frame_no = frame_no;
 }
 
 // ---- glam pieces used by the shader table -------------------------------------

@@ -190,7 +190,10 @@ __device__ __forceinline__ void bin_one(const RasterArgs &a, uint32_t *s_hist, c
 // The fan entries with VIRTUAL indices [lo, hi) (FanMap: the used parts of the fan regions laid end to end; index ntris
 // + ... ), by the waves of a BIN_WG-thread workgroup: a wave takes 64 consecutive ones per round, BIN_PF rounds at a time --
 // their bboxes are fetched up front (the loop is latency-bound otherwise).
-constexpr int BIN_PF = 4;
+#ifndef FRR_BIN_PF
+#define FRR_BIN_PF 4
+#endif
+constexpr int BIN_PF = FRR_BIN_PF;
 template <bool SCATTER, class PUT>
 __device__ __forceinline__ void bin_walk_fans(const RasterArgs &a, uint32_t *s_hist, const FanMap &fm, const uint4 *__restrict__ pbox,
                                               uint32_t lo, uint32_t hi, int lane, uint32_t wave, const PUT &put)
@@ -502,9 +505,10 @@ __device__ __forceinline__ SetupOut setup_unclipped(const float pos[3][4], const
 __device__ __forceinline__ void geom_bookkeeping(const GeomArgs &g)
 {
     Counters *cnt = g.cnt;
-    totals_for_frame(cnt, g.frame_no);
-    GeomTab &me = cnt->gtab[g.gpar], &prev = cnt->gtab[g.gpar ^ 1];
-    if (me.frame_no == g.frame_no) { cnt->tot_frag_covered += me.frag_covered; cnt->tot_frag_nan += me.frag_nan; }
+    Lane &L = cnt->lane[g.lane];
+    totals_for_frame(cnt, L, g.frame_no);
+    GeomTab &me = L.gtab[g.gpar], &prev = L.gtab[g.gpar ^ 1];
+    if (me.frame_no == g.frame_no) { L.tot_frag_covered += me.frag_covered; L.tot_frag_nan += me.frag_nan; }
     me.frag_covered = 0ull; me.frag_nan = 0ull;
     me.tri_base = prev.frame_no == g.frame_no ? prev.tri_base + prev.n_emit : 0u; // the previous pass's triangles precede this pass's (its block sums are scanned by now)
     me.n_emit = 0u; me.need_fans = 0u;
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     const uint32_t bid = blockIdx.x;
     const uint32_t t = bid * GEOM_BLOCK + threadIdx.x;
     const uint32_t first_bad = seq_first_bad(g.cnt);   // (tested below, where the vertex loads are waited for anyway)
-    GeomTab *const gt = &g.cnt->gtab[g.gpar];
+    GeomTab *const gt = &g.cnt->lane[g.lane].gtab[g.gpar];
     if (threadIdx.x == 0) s_ncl = 0; // ordered before its use by the barriers inside block_excl_scan256
     float pos[3][4];
     float ctx[3][K > 0 ? K : 1];
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_clip(GeomArgs g, DevUniform
     __shared__ int32_t s_ckey[GEOM_BLOCK / 64][CLIP_MAXV];
     __shared__ float s_cv[GEOM_BLOCK / 64][CLIP_MAXV][7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)];
     if (seq_cancelled(g.cnt, g.seq, g.epoch, false)) return;
-    const uint32_t n = g.cnt->gtab[g.gpar].clip_q;
+    const uint32_t n = g.cnt->lane[g.lane].gtab[g.gpar].clip_q;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t stride = gridDim.x * (GEOM_BLOCK / 64);
     for (uint32_t e = blockIdx.x * (GEOM_BLOCK / 64) + (uint32_t)w; e < n; e += stride) {
@@ -722,7 +726,7 @@ __global__ void k_geom_empty(GeomArgs g)
 // Exclusive scan of the draw's block sums (in place: they become Counters::block_prefix), by one workgroup of 1024
 // threads (the extra workgroup of k_bin_seg, or k_geom_scan on its own); publishes n_emit and raises the capacity flag
 // when the draw asked for more fan slots than there are.
-__device__ __forceinline__ void geom_scan(const uint32_t *sums, uint32_t *prefix, uint32_t nblocks, Counters *cnt, int gpar, uint32_t fan_cap, uint32_t seq, uint32_t epoch)
+__device__ __forceinline__ void geom_scan(const uint32_t *sums, uint32_t *prefix, uint32_t nblocks, Counters *cnt, int tab_lane, int gpar, uint32_t fan_cap, uint32_t seq, uint32_t epoch)
 {
     __shared__ uint32_t s_sw[16];
     __shared__ uint32_t s_carry;
@@ -745,7 +749,7 @@ __device__ __forceinline__ void geom_scan(const uint32_t *sums, uint32_t *prefix
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        GeomTab &gt = cnt->gtab[gpar];
+        GeomTab &gt = cnt->lane[tab_lane].gtab[gpar];
         gt.n_emit = s_carry;
         uint32_t fans = 0;   // the fullest region decides: every region has fan_cap / FAN_REGIONS slots
 #pragma unroll
@@ -755,10 +759,10 @@ __device__ __forceinline__ void geom_scan(const uint32_t *sums, uint32_t *prefix
         if (fans > fan_cap / FAN_REGIONS) seq_fail(cnt, seq, epoch, 1u);
     }
 }
-__global__ __launch_bounds__(1024) void k_geom_scan(const uint32_t *sums, uint32_t *prefix, uint32_t nblocks, Counters *cnt, int gpar, uint32_t fan_cap, uint32_t seq, uint32_t epoch)
+__global__ __launch_bounds__(1024) void k_geom_scan(const uint32_t *sums, uint32_t *prefix, uint32_t nblocks, Counters *cnt, int lane, int gpar, uint32_t fan_cap, uint32_t seq, uint32_t epoch)
 {
     if (seq_cancelled(cnt, seq, epoch, false)) return;
-    geom_scan(sums, prefix, nblocks, cnt, gpar, fan_cap, seq, epoch);
+    geom_scan(sums, prefix, nblocks, cnt, lane, gpar, fan_cap, seq, epoch);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -772,7 +776,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(RasterArgs a, uint32_t fan_cap)
 {
     if (seq_cancelled(a.cnt, a.seq, a.epoch, false)) return;
-    const FanMap fm = fan_map(&a.cnt->gtab[a.gpar], fan_cap);
+    const FanMap fm = fan_map(&a.cnt->lane[a.lane].gtab[a.gpar], fan_cap);
     const uint32_t n = fan_map_total(fm);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6);
@@ -838,10 +842,11 @@ __global__ __launch_bounds__(1024) void k_tile_scan(RasterArgs a, uint32_t ntile
     if (threadIdx.x == 0) {
         uint32_t total = s_carry;
         a.tile_offsets[ntiles] = total;
-        a.cnt->bin_total = total;
-        totals_for_frame(a.cnt, a.frame_no);
+        Lane &L = a.cnt->lane[a.lane];
+        L.bin_total = total;
+        totals_for_frame(a.cnt, L, a.frame_no);
         if (total > a.bin_cap) seq_fail(a.cnt, a.seq, a.epoch, 2u);
-        else a.cnt->tot_bin_entries += total;
+        else L.tot_bin_entries += total;
     }
 }
 
@@ -874,11 +879,11 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     if (seq_is_cancelled(first_bad, a.seq, a.epoch, false)) return;
     // do_scan: the launch's LAST workgroup scans the geometry kernel's block sums instead (the tile kernel's resolve
     // needs the prefix for triangle ids; here it costs no launch and sits on nobody's critical path)
-    if (scan_wg) { geom_scan(block_sums, block_prefix, nblocks, a.cnt, a.gpar, fan_cap, a.geom_seq, a.epoch); return; }
-    if (g == 0 && threadIdx.x == 0) bin_bookkeeping(a.cnt, a.bpar, a.frame_no);
+    if (scan_wg) { geom_scan(block_sums, block_prefix, nblocks, a.cnt, a.lane, a.gpar, fan_cap, a.geom_seq, a.epoch); return; }
+    if (g == 0 && threadIdx.x == 0) bin_bookkeeping(a.cnt, a.lane, a.bpar, a.frame_no);
     __syncthreads();
     // a workgroup's chunk: a range of geometry blocks (their dense entries) and a range of the used fan entries
-    const FanMap fm = fan_map(&a.cnt->gtab[a.gpar], fan_cap);
+    const FanMap fm = fan_map(&a.cnt->lane[a.lane].gtab[a.gpar], fan_cap);
     const uint32_t bpw = (nblocks + G - 1) / G;
     const uint32_t b_lo = min(nblocks, g * bpw), b_hi = min(nblocks, b_lo + bpw);
     const uint32_t nfan = fm.pre[FAN_REGIONS];
@@ -904,7 +909,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
     // the region is reserved now, but only a workgroup whose records do not all fit the LDS staging has to know where it
     // starts before it places them: the others walk while the atomic is in flight
     unsigned long long before = 0;
-    if (threadIdx.x == 0) before = atomicAdd(&a.cnt->btab[a.bpar].seg_total, (unsigned long long)total);
+    if (threadIdx.x == 0) before = atomicAdd(&a.cnt->lane[a.lane].btab[a.bpar].seg_total, (unsigned long long)total);
     uint32_t base = 0;
     if (total > stage_cap) {
         if (threadIdx.x == 0) s_base = bin_region_of(a, before, total);

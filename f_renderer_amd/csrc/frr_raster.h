@@ -76,7 +76,7 @@ __device__ __forceinline__ uint32_t slot_of_emission(const GeomTab *cnt, uint32_
     return n == 1u ? a : nt + cnt->fanbase[a] + q;
 }
 
-__device__ __forceinline__ const GeomTab *gtab_of(const RasterArgs &a) { return &a.cnt->gtab[a.gpar]; }
+__device__ __forceinline__ const GeomTab *gtab_of(const RasterArgs &a) { return &a.cnt->lane[a.lane].gtab[a.gpar]; }
 
 struct TileCtx {
     int tile, ltile, lx0, ly0, tw, th, ax0, ay0; // tile index in the window / among the rank's own tiles; window-local origin, extent, absolute pixel origin
@@ -348,8 +348,8 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
         const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e].x);
         sweep_triangle(a, c, t, order_id(gtab_of(a), t), lane, s_key, n_cov, n_nan, &s_nanflag);
     }
-    if (lane == 0 && n_cov) atomicAdd(&a.cnt->gtab[a.gpar].frag_covered, (unsigned long long)n_cov);
-    if (n_nan) atomicAdd(&a.cnt->gtab[a.gpar].frag_nan, (unsigned long long)n_nan);
+    if (lane == 0 && n_cov) atomicAdd(&a.cnt->lane[a.lane].gtab[a.gpar].frag_covered, (unsigned long long)n_cov);
+    if (n_nan) atomicAdd(&a.cnt->lane[a.lane].gtab[a.gpar].frag_nan, (unsigned long long)n_nan);
     __syncthreads();
     if (s_nanflag != 0u) { // (uniform: read after the barrier)
         tile_nan_begin(c, s_key, s_nanL);
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             // single address costs ~17 ns each, serialised across the whole launch; hence the slots.)
             const uint32_t ntiles = gridDim.x;
             s_ebase = total <= a.ent_slot ? (uint32_t)c.ltile * a.ent_slot
-                                          : ntiles * a.ent_slot + atomicAdd(&a.cnt->btab[a.bpar].ent_cursor, total);
+                                          : ntiles * a.ent_slot + atomicAdd(&a.cnt->lane[a.lane].btab[a.bpar].ent_cursor, total);
         }
         __syncthreads();
         c.beg = __builtin_amdgcn_readfirstlane(s_ebase); // this tile's range of the near-first copy (bins2)
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         wave_lds_fence(); // staging is rewritten by the next step
     }
     FRR_T(1);
-    if (lane == 0 && n_cov) atomicAdd(&a.cnt->gtab[a.gpar].frag_covered, (unsigned long long)n_cov);
+    if (lane == 0 && n_cov) atomicAdd(&a.cnt->lane[a.lane].gtab[a.gpar].frag_covered, (unsigned long long)n_cov);
 #ifdef FRR_DEBUG_COUNTERS
     d_rt2 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         atomicAdd(d + 8, (unsigned long long)d_pre); atomicAdd(d + 9, (unsigned long long)d_win); atomicAdd(d + 10, (unsigned long long)d_rebuild);
     }
 #endif
-    if (n_nan) atomicAdd(&a.cnt->gtab[a.gpar].frag_nan, (unsigned long long)n_nan);
+    if (n_nan) atomicAdd(&a.cnt->lane[a.lane].gtab[a.gpar].frag_nan, (unsigned long long)n_nan);
     __syncthreads();
     if (s_nanflag != 0u) {
         // NaN fragments (renderer.rs:363-366): the pixels they cover are decided by a second, unculled sweep of ALL the

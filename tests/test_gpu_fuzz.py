@@ -19,7 +19,7 @@ def run_case(fr, scenes, cref, rng, small_lists=False):
         tris[:: max(1, n // 7), int(rng.integers(0, 3)), 3] = 0.0
     if rng.random() < 0.2:                                   # vertices whose screen position overflows: fans of NaN-depth fragments
         tris[:: max(1, n // 5), int(rng.integers(0, 3)), 0] = 3e38
-    opts = {"clip_queue": int(rng.integers(-1, 2)), "raster_nw": int(rng.choice([0, 0, 3, 4, 8, 16])), "overlap": int(rng.integers(0, 2))}
+    opts = {"clip_queue": int(rng.integers(-1, 2)), "raster_nw": int(rng.choice([0, 0, 3, 4, 8, 16])), "overlap": int(rng.integers(0, 3)), "frames_in_flight": int(rng.integers(1, 3))}
     if small_lists:                                          # force replays: tiny work lists
         opts["bin_capacity"] = int(rng.integers(64, 4000))
         opts["fan_capacity"] = int(rng.integers(8, 512))

@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
-"""Dev tool: copy what tools/refresh_profiles.sh left in gpurun_out/final2/ into the committed profiles/ (r02_*)."""
+"""Dev tool: copy what tools/refresh_profiles.sh left in gpurun_out/final3/ into the committed profiles/ (r03_*)."""
 import glob, json, os, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(R, "gpurun_out", "final2")
+F = os.path.join(R, "gpurun_out", "final3")
 P = os.path.join(R, "profiles")
-TAG = "r02"
+TAG = "r03"
 one = lambda pat: sorted(glob.glob(os.path.join(F, pat)))[-1]
 shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"{TAG}_bench.json"))
 shutil.copy(os.path.join(F, "configs.json"), os.path.join(P, f"{TAG}_configs.json"))
 shutil.copy(os.path.join(F, "bench_in_flight.json"), os.path.join(P, f"{TAG}_bench_in_flight.json"))
 shutil.copy(os.path.join(F, "partition_times.json"), os.path.join(P, f"{TAG}_partition_times.json"))
 shutil.copy(os.path.join(F, "shapes.log"), os.path.join(P, f"{TAG}_tile_kernel_shapes.txt"))
+shutil.copy(os.path.join(F, "overlap_modes.txt"), os.path.join(P, f"{TAG}_overlap_modes.txt"))
+shutil.copy(os.path.join(F, "overlap_cfg5_kernel_timeline.txt"), os.path.join(P, f"{TAG}_overlap_cfg5_kernel_timeline.txt"))
 WL = {"headline": "random_1M_tris_1920x1080_depth", "cfg4": "random_1M_tris_4096x4096_depth", "cfg5": "sheets_259k_tris_3840x2160_blinn"}
 os.makedirs(os.path.join(P, f"{TAG}_pmc"), exist_ok=True)
 traffic = os.path.join(P, "pmc_traffic.json")
@@ -21,7 +23,10 @@ for w, name in WL.items():
     shutil.copy(os.path.join(F, f"timeline_{w}.log"), os.path.join(P, f"{TAG}_{w}_tile_timeline.txt"))
     for src, dst in (("fetch", "fetch_size"), ("write", "write_size"), ("sq1", "sq_pass1"), ("sq2", "sq_pass2")):
         shutil.copy(one(f"{src}_{w}/*/*counter_collection.csv"), os.path.join(P, f"{TAG}_pmc", f"{w}_{dst}_counter_collection.csv"))
-    subprocess.check_call([sys.executable, os.path.join(R, "tools", "make_pmc_traffic.py"), os.path.join(F, f"fetch_{w}"), os.path.join(F, f"write_{w}"), name, traffic])
+    import re
+    m = re.search(r"'bin_entries': (\d+)", open(os.path.join(F, f"f_{w}.log")).read())   # (tools/pmc_frame.py prints the frame's statistics)
+    subprocess.check_call([sys.executable, os.path.join(R, "tools", "make_pmc_traffic.py"), os.path.join(F, f"fetch_{w}"), os.path.join(F, f"write_{w}"), name, traffic,
+                           m.group(1) if m else "0"])
     subprocess.check_call([sys.executable, os.path.join(R, "tools", "pmc_summary.py"), os.path.join(F, f"sq1_{w}"), os.path.join(F, f"sq2_{w}"),
                            "--json", os.path.join(P, f"{TAG}_pmc", f"{w}_sq_summary.json")], stdout=subprocess.DEVNULL)
 b = json.load(open(os.path.join(P, f"{TAG}_bench.json")))

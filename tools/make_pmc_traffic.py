@@ -5,10 +5,15 @@ request for wide (16 B/lane) loads, i.e. exactly half -- calibrated here on the 
 workloads, which reads the 48,000,000-byte triangle list once with dwordx4 loads -- so fetch bytes are doubled for the
 streaming kernels (geometry, binning).  The tile kernel's reads are scattered 64-byte record gathers; that pattern was
 calibrated with k_debug_gather (tools/pmc_gather_calib.py, profiles/r01_pmc: 8M distinct 64-B records = 524,288 KiB
-true, FETCH_SIZE 523,779 KiB = 0.999x), so its FETCH_SIZE is used as is.  WRITE_SIZE is exact for full-line stores.
+true, FETCH_SIZE 523,779 KiB = 0.999x), so that part of its FETCH_SIZE is used as is; its reads of the (triangle, tile)
+lists, however, are contiguous 16-byte-per-lane loads (the binning's records in the pre-pass, the near-first copy in the
+main loop: 2 x 16 B per list entry), which count half like any wide streaming load: with the number of list entries of the
+frame (6th argument, from frr_get_stats) the entry carries `fetch_list_correction_bytes` = 16 B x entries (the missing
+half of 32 B x entries) and `hbm_bytes_per_launch` includes it -- an upper bound, since entries served by the segment
+table walk of lightly loaded tiles are read once.  WRITE_SIZE is exact for full-line stores.
 Every entry carries the digest of the kernel sources it was measured on (`_source_sha`): bench.py reports the
 traffic only while the library it runs was built from the same sources.
-usage: make_pmc_traffic.py <fetch_dir> <write_dir> <workload> <out.json>"""
+usage: make_pmc_traffic.py <fetch_dir> <write_dir> <workload> <out.json> [bin_entries]"""
 import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
@@ -36,6 +41,7 @@ def mean_counter(d, name):
 
 def main():
     fd, wd, workload, out = sys.argv[1:5]
+    bin_entries = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     fetch, write = mean_counter(fd, "FETCH_SIZE"), mean_counter(wd, "WRITE_SIZE")
     res = json.load(open(out)) if os.path.exists(out) else {}
     entry = {"_source_sha": source_sha()}
@@ -50,9 +56,10 @@ def main():
         name = "k_raster" if short.startswith("k_raster_span") and "false" in short else short
         f_kib, w_kib = fetch[k], write.get(k, 0.0)
         corr = 1.0 if short.startswith("k_raster") else 2.0
+        lists = 16 * bin_entries if short.startswith("k_raster") else 0
         entry[name] = {"kernel": short, "fetch_size_kib": round(f_kib, 1), "write_size_kib": round(w_kib, 1),
-                       "fetch_correction": corr,
-                       "hbm_bytes_per_launch": round((corr * f_kib + w_kib) * 1024)}
+                       "fetch_correction": corr, "fetch_list_correction_bytes": lists,
+                       "hbm_bytes_per_launch": round((corr * f_kib + w_kib) * 1024) + lists}
     res[workload] = entry
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(workload, json.dumps(entry.get("k_raster")))

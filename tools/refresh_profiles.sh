@@ -1,10 +1,10 @@
 #!/bin/bash
-# Dev tool, run on the GPU box (gpurun): everything profiles/r02_* is generated from, written under gpurun_out/final2/.
+# Dev tool, run on the GPU box (gpurun): everything profiles/r03_* is generated from, written under gpurun_out/final3/.
 #   gpurun -- 'bash tools/refresh_profiles.sh'   then   python tools/collect_profiles.py
 # rocprofv3: the program itself follows `--` (python3 ...), kernel trace only next to --pmc (separate passes per counter set).
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/final2; rm -rf $O; mkdir -p $O
+O=gpurun_out/final3; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
 python bench.py --in-flight --also none --cpu-baseline-seconds 0 > $O/bench_in_flight.json 2>> $O/bench.err || exit 1
 for w in headline cfg4 cfg5; do
@@ -14,6 +14,9 @@ for w in headline cfg4 cfg5; do
   FRAMES=4 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_WAIT_ANY -d $O/sq1_$w --output-format csv -- python3 tools/pmc_frame.py $w > $O/s1_$w.log 2>&1 || exit 1
   FRAMES=4 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d $O/sq2_$w --output-format csv -- python3 tools/pmc_frame.py $w > $O/s2_$w.log 2>&1 || exit 1
 done
+for w in headline cfg4 cfg5; do for p in - 3,8; do CFG=$w PART=$p N=100 python tools/overlap_probe.py 2>&1 | grep "overlap=" >> $O/overlap_modes.txt || exit 1; done; done
+OVERLAP=1 CFG=cfg5 N=40 rocprofv3 --kernel-trace -d $O/kt_overlap -o kt --output-format csv -- python3 tools/overlap_probe.py > $O/kt_overlap.log 2>&1 || exit 1
+python tools/trace_timeline.py $O/kt_overlap/kt_kernel_trace.csv 4 > $O/overlap_cfg5_kernel_timeline.txt || exit 1
 timeout -k 10 600 python tools/run_configs.py --json $O/configs.json > $O/cfg.log 2>&1 || exit 1
 python tools/partition_times.py --json $O/partition_times.json > $O/part.log 2>&1 || exit 1
 python tools/exp_shapes.py headline cfg4 cfg5 > $O/shapes.log 2>&1 || exit 1
