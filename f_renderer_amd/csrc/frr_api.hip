@@ -1600,7 +1600,7 @@ int frr_debug_rcp_check(frr_ctx *c, uint32_t lo_bits, uint32_t hi_bits, uint64_t
 int frr_debug_tiles(frr_ctx *c, unsigned long long *out, uint32_t *ntiles)
 {
     if (!c || !out || !ntiles || !c->dbg_tiles) return FRR_ERR_INVALID;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc = drain(c); if (rc != FRR_OK) return rc; }
     HIP_TRY(c, hipMemcpy(out, c->dbg_tiles, (size_t)c->max_tiles * 64, hipMemcpyDeviceToHost));
     *ntiles = c->max_tiles;
     return FRR_OK;

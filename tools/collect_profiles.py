@@ -9,10 +9,11 @@ one = lambda pat: sorted(glob.glob(os.path.join(F, pat)))[-1]
 shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"{TAG}_bench.json"))
 shutil.copy(os.path.join(F, "configs.json"), os.path.join(P, f"{TAG}_configs.json"))
 shutil.copy(os.path.join(F, "bench_in_flight.json"), os.path.join(P, f"{TAG}_bench_in_flight.json"))
+shutil.copy(os.path.join(F, "bench_serial.json"), os.path.join(P, f"{TAG}_bench_serial.json"))
 shutil.copy(os.path.join(F, "partition_times.json"), os.path.join(P, f"{TAG}_partition_times.json"))
 shutil.copy(os.path.join(F, "shapes.log"), os.path.join(P, f"{TAG}_tile_kernel_shapes.txt"))
 shutil.copy(os.path.join(F, "overlap_modes.txt"), os.path.join(P, f"{TAG}_overlap_modes.txt"))
-shutil.copy(os.path.join(F, "overlap_cfg5_kernel_timeline.txt"), os.path.join(P, f"{TAG}_overlap_cfg5_kernel_timeline.txt"))
+shutil.copy(os.path.join(F, "frames_in_flight_kernel_timeline.txt"), os.path.join(P, f"{TAG}_frames_in_flight_kernel_timeline.txt"))
 WL = {"headline": "random_1M_tris_1920x1080_depth", "cfg4": "random_1M_tris_4096x4096_depth", "cfg5": "sheets_259k_tris_3840x2160_blinn"}
 os.makedirs(os.path.join(P, f"{TAG}_pmc"), exist_ok=True)
 traffic = os.path.join(P, "pmc_traffic.json")
@@ -20,6 +21,7 @@ if os.path.exists(traffic):
     os.remove(traffic)
 for w, name in WL.items():
     shutil.copy(one(f"kt_{w}/*/*kernel_stats.csv"), os.path.join(P, f"{TAG}_{w}_kernel_stats.csv"))
+    shutil.copy(one(f"kts_{w}/*/*kernel_stats.csv"), os.path.join(P, f"{TAG}_{w}_kernel_stats_serial.csv"))
     shutil.copy(os.path.join(F, f"timeline_{w}.log"), os.path.join(P, f"{TAG}_{w}_tile_timeline.txt"))
     for src, dst in (("fetch", "fetch_size"), ("write", "write_size"), ("sq1", "sq_pass1"), ("sq2", "sq_pass2")):
         shutil.copy(one(f"{src}_{w}/*/*counter_collection.csv"), os.path.join(P, f"{TAG}_pmc", f"{w}_{dst}_counter_collection.csv"))

@@ -8,7 +8,7 @@ from f_renderer_amd import scenes
 cfg = scenes.build_config(os.environ.get("CFG", "headline"))
 W, H = cfg["W"], cfg["H"]
 N = int(os.environ.get("N", "200"))
-modes = [(int(os.environ["OVERLAP"]), int(os.environ.get("FIF", "2")))] if os.environ.get("OVERLAP") else [(0, 1), (1, 1), (2, 1)]
+modes = [(int(os.environ["OVERLAP"]), int(os.environ.get("FIF", "2")))] if os.environ.get("OVERLAP") else [(0, 1), (2, 1), (1, 1), (0, 2)]
 for overlap, fif in modes:
     r = fr.Renderer(W, H)
     r.set_option("overlap", overlap)
