@@ -208,7 +208,11 @@ class Run:
         self.vs, self.ps = getattr(fr, "VS_" + cfg["vs"]), getattr(fr, "PS_" + cfg["ps"])
         self.K = fr.lib().frr_vs_num_varyings(self.vs)
         self.shaded = cfg["ps"] != "DEPTH"
-        self.stream = torch.cuda.Stream()
+        # ONE torch stream for every workload of this process: a process's HIP streams share a handful of hardware queues, and
+        # the library's second frame stream must not end up on the same queue as the caller's
+        if not hasattr(Run, "_stream"):
+            Run._stream = torch.cuda.Stream()
+        self.stream = Run._stream
         with torch.cuda.stream(self.stream):
             # frame targets live in torch tensors (plumbing: device memory + the gather's operands); the height is
             # padded to a whole number of tile rows per rank so that every rank's slab has the same size

@@ -586,6 +586,11 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
     const bool use_clipq = nt > 0 && (c->clip_queue > 0 || (c->clip_queue < 0 && c->clip_queue_auto));
     if (use_clipq && (rc = ensure(c, S.clipq, S.clipq_cap, (size_t)nt)) != FRR_OK) return rc;
     if ((rc = scan_now(c)) != FRR_OK) return rc;   // the previous pass's n_emit feeds this pass's tri_base
+    if (on_g && !c->gstream) {
+        // created on first use: a process maps its HIP streams onto a handful of hardware queues, and two streams that
+        // share one run nothing beside each other -- a ctx that never needs this stream does not take a queue for it
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking));
+    }
     if (on_g != f.on_g) {
         // this pass changes streams: it follows the previous pass's geometry + binning (tri_base, fan cursors)
         hipEvent_t e = c->ev_bin[++c->bin_serial & 3];
@@ -913,15 +918,6 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     c->device = device; c->W = width; c->H = height;
     if (stream) c->stream = (hipStream_t)stream;
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FRR_ERR_HIP; } c->own_stream = true; }
-    {
-        // geometry + binning are short and HBM-bound; beside a tile kernel that fills every workgroup slot they would get
-        // slots only as its workgroups retire (measured: 27 -> 88 us), so their stream has the higher priority
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const char *pe = getenv("FRR_GSTREAM_PRIO");   // dev: 0 = default priority
-        const int prio = (pe && atoi(pe) == 0) ? 0 : hi;
-        if (hipStreamCreateWithPriority(&c->gstream, hipStreamNonBlocking, prio) != hipSuccess) { frr_destroy(c); return FRR_ERR_HIP; }
-    }
     const size_t npx = (size_t)width * height;
     bool ok = hipMalloc((void **)&c->own_color[0], npx * 4) == hipSuccess && hipMalloc((void **)&c->own_depth[0], npx * 4) == hipSuccess &&
               hipMalloc((void **)&c->own_tri_id[0], npx * 4) == hipSuccess && hipMalloc((void **)&c->cnt, sizeof(Counters)) == hipSuccess;

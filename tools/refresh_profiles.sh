@@ -4,7 +4,8 @@
 # rocprofv3: the program itself follows `--` (python3 ...), kernel trace only next to --pmc (separate passes per counter set).
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/final3; rm -rf $O; mkdir -p $O
+O=gpurun_out/final3; [ -z "$PART2" ] && rm -rf $O; mkdir -p $O
+if [ -z "$PART2" ]; then
 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
 FRR_FRAMES_IN_FLIGHT=1 FRR_OVERLAP=0 python bench.py --cpu-baseline-seconds 0 > $O/bench_serial.json 2>> $O/bench.err || exit 1   # one frame at a time, one stream (round 2's mode)
 python bench.py --in-flight --also none --cpu-baseline-seconds 0 > $O/bench_in_flight.json 2>> $O/bench.err || exit 1
@@ -20,7 +21,9 @@ for w in headline cfg4 cfg5; do
   FRAMES=4 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d $O/sq2_$w --output-format csv -- python3 tools/pmc_frame.py $w > $O/s2_$w.log 2>&1 || exit 1
   unset FRR_FRAMES_IN_FLIGHT FRR_OVERLAP
 done
-for w in headline cfg4 cfg5; do for p in - 3,8; do CFG=$w PART=$p N=100 python tools/overlap_probe.py 2>&1 | grep "overlap=" >> $O/overlap_modes.txt || exit 1; done; done
+fi
+rm -f $O/overlap_modes.txt
+for w in headline cfg4 cfg5; do for p in "" 3,8; do CFG=$w PART=$p N=100 python tools/overlap_probe.py 2>&1 | grep "overlap=" >> $O/overlap_modes.txt || exit 1; done; done
 OVERLAP=2 FIF=2 CFG=headline N=40 rocprofv3 --kernel-trace -d $O/kt_overlap -o kt --output-format csv -- python3 tools/overlap_probe.py > $O/kt_overlap.log 2>&1 || exit 1
 python tools/trace_timeline.py $O/kt_overlap/kt_kernel_trace.csv 4 > $O/frames_in_flight_kernel_timeline.txt || exit 1
 timeout -k 10 600 python tools/run_configs.py --json $O/configs.json > $O/cfg.log 2>&1 || exit 1
