@@ -226,6 +226,9 @@ class Run:
             self.r = self.make_renderer(local_rank)
             if dist is not None:   # (N = 1: the library's own targets -- two sets, so that two frames are in flight)
                 self.r.bind_targets(self.color[0].data_ptr(), self.depth[0].data_ptr(), self.tri_id[0].data_ptr())
+                # N > 1: the same two frames in flight on the caller-bound target sets (three of them, rotating): frames run on
+                # the library's private streams, the exchange of a frame is fenced on this stream (frr_frame_fence)
+                self.r.set_option("bound_targets_in_flight", 1)
             self.r.set_partition(rank, world, blocked=True)   # contiguous slabs: the gather needs no staging copies
             self.dev_in = torch.from_numpy(cfg["mesh"]).to("cuda")  # resident in HBM before timing
             self.mesh = self.r.bind_mesh_device(self.dev_in.data_ptr(), self.ntris, self.vs, keepalive=self.dev_in)
@@ -275,7 +278,9 @@ class Run:
         self.r.clear((30, 30, 30, 255), 0.0)
         self.r.draw(self.mesh, self.ps)
         if g is not None:
-            # owned slabs -> the RCCL gather to rank 0 (final image only), overlapped with the next frames
+            # owned slabs -> the RCCL exchange to rank 0 (final image only), overlapped with the next frames: this stream
+            # waits for the frame (no host wait), the exchange follows it
+            self.r.frame_fence(self.stream.cuda_stream)
             self.inflight[s] = g[s].start(self.planes_of(s))
             if sync_gather:
                 self.final = g[s].finish(self.inflight[s])
@@ -371,6 +376,7 @@ class Run:
             render_us = gather_us = None
             if self.gathers is not None:
                 s = self.step(gather=False)
+                self.r.frame_fence(self.stream.cuda_stream)
                 ids_final = self.gather_ids([self.tri_id[s]])
                 torch.cuda.synchronize()
                 if self.rank == 0:
@@ -460,6 +466,11 @@ class Run:
 
 def main():
     args = parse_args()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_dist:
+        # a rank keeps two frames in flight on the library's two private streams beside this program's own stream and RCCL's:
+        # HIP maps a process's streams onto 4 hardware queues by default, and two streams that share one run nothing beside
+        # each other (measured: a rank of 8 of the 4K textured frame 80 us with 4 queues, 64 us with 8).  Before HIP starts.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -475,6 +486,7 @@ def main():
     dist = None
     saved_stdout_fd = None
     if world > 1 or args.force_dist:
+
         import torch.distributed as dist
         # RCCL prints a version banner on file descriptor 1 when its communicator is created; this program's
         # stdout is ONE JSON line, so everything else written to fd 1 until then goes to stderr

@@ -121,6 +121,7 @@ SIGNATURES = {
     "frr_geometry": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_uint64)]),
     "frr_raster": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "frr_draw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "frr_frame_fence": (C.c_int, [C.c_void_p, C.c_void_p]),
     "frr_sync": (C.c_int, [C.c_void_p]),
     "frr_readback": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frr_readback_setup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, _P(C.c_uint64)]),

@@ -158,9 +158,14 @@ struct frr_ctx {
     // except through this library (frr_readback, frr_target_ptrs, which join the streams first), so the only visible
     // change is that frr_target_ptrs' pointers are those of the CURRENT frame.  Caller-bound targets: one set, one stream.
     uint8_t *own_color[2] = {}; float *own_depth[2] = {}; uint32_t *own_tri_id[2] = {};
-    hipStream_t tstream2 = nullptr;  // tile kernels / clears of own target set 1
-    hipEvent_t ev_t2 = nullptr;      // joins tstream2 into `stream`
-    bool t2_dirty = false;           // tstream2 holds work `stream` has not waited for
+    hipStream_t tstream2 = nullptr;  // everything of the frames that use own target set 1 (or, option bound_targets_in_flight, of every other frame)
+    hipStream_t tstream1 = nullptr;  // option bound_targets_in_flight: the frames in between (the caller's stream then carries no frame work at all)
+    hipEvent_t ev_t2 = nullptr, ev_t1 = nullptr;   // join them into a caller's stream
+    bool t2_dirty = false, t1_dirty = false;       // they hold work `stream` has not waited for
+    bool t2_xdirty = false, t1_xdirty = false;     // ... that the stream of the latest frr_frame_fence has not waited for
+    hipStream_t xfence = nullptr;                  //     (that stream)
+    bool bound_in_flight = false;    // option bound_targets_in_flight: frames on caller-bound targets alternate between the two private streams too;
+                                     // the caller binds another target set for each of two consecutive frames and fences its reads (frr_frame_fence)
     int frames_in_flight = 2;        // option frames_in_flight (1: one target set, everything on the caller's stream)
     Counters *cnt = nullptr;
     FrameState fs;
@@ -170,7 +175,9 @@ struct frr_ctx {
     // stream waits for it before it overwrites a workspace that kernel reads), ev_bin[k & 3] when binning k is done
     hipEvent_t ev_bin[4] = {}, ev_join = nullptr;
     uint64_t bin_serial = 0;
-    bool need_join = true;          // the second stream has not yet waited for what the caller put on `stream` (mesh data)
+    // inputs the caller wrote on `stream` (a device-bound mesh) must be visible to the ctx's private streams: every bind
+    // starts a new epoch, and a private stream waits for `stream` once per epoch before its next geometry pass
+    uint32_t join_epoch = 1, joined_g = 0, joined_t1 = 0, joined_t2 = 0;
     // command log since the last synchronisation point / frr_clear (finish(): replay)
     std::vector<Cmd> log;
     uint32_t next_seq = 1, epoch = 1;
@@ -235,33 +242,55 @@ bool own_targets(const frr_ctx *c)
     const FrameState &f = c->fs;
     return f.color == c->own_color[f.tset] && f.depth == c->own_depth[f.tset] && f.tri_id == c->own_tri_id[f.tset];
 }
-hipStream_t tstream_of(const frr_ctx *c) { return (c->tstream2 && c->fs.tset == 1 && own_targets(c)) ? c->tstream2 : c->stream; }
+// do consecutive frames (frr_clear) alternate between two streams / target sets / workspace sets / lanes?
+bool frames_alternate(const frr_ctx *c) { return c->frames_in_flight == 2 && (own_targets(c) || c->bound_in_flight); }
+hipStream_t tstream_of(const frr_ctx *c)
+{
+    if (c->bound_in_flight && !own_targets(c) && c->tstream1 && c->tstream2) return c->fs.tset ? c->tstream2 : c->tstream1;
+    return (c->tstream2 && c->fs.tset == 1 && own_targets(c)) ? c->tstream2 : c->stream;
+}
 // the stream of the latest geometry pass and of the binning that follows it: the second stream, or the targets' stream
 hipStream_t gstream_of(const frr_ctx *c) { return c->fs.on_g ? c->gstream : tstream_of(c); }
 // do passes ever run beside each other on this ctx (workspace sets then carry events)?
-bool multi_stream(const frr_ctx *c) { return c->g_used || c->tstream2 != nullptr; }
+bool multi_stream(const frr_ctx *c) { return c->g_used || c->tstream2 != nullptr || c->tstream1 != nullptr; }
 
 // all streams idle
 int drain(frr_ctx *c)
 {
     if (c->gstream) HIP_TRY(c, hipStreamSynchronize(c->gstream));
     if (c->tstream2) HIP_TRY(c, hipStreamSynchronize(c->tstream2));
+    if (c->tstream1) HIP_TRY(c, hipStreamSynchronize(c->tstream1));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->t2_dirty = false;
+    c->t2_dirty = c->t1_dirty = c->t2_xdirty = c->t1_xdirty = false;
     c->g_used = false;
     for (GeomSet &S : c->gset) S.reader_pending = false;
     for (BinSet &B : c->bset) B.reader_pending = false;
     return FRR_OK;
 }
-// the caller's stream waits for the second tile stream: what the caller enqueues next sees every frame issued so far
-int join_tile_streams(frr_ctx *c)
+// a caller's stream waits for the ctx's frame streams: what is enqueued on it next sees every frame issued so far
+int fence_stream(frr_ctx *c, hipStream_t st)
 {
-    if (!c->t2_dirty) return FRR_OK;
-    HIP_TRY(c, hipEventRecord(c->ev_t2, c->tstream2));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_t2, 0));
-    c->t2_dirty = false;
+    const bool own = st == c->stream;
+    if (!own && st != c->xfence) { c->xfence = st; c->t1_xdirty = c->tstream1 != nullptr; c->t2_xdirty = c->tstream2 != nullptr; }
+    if (c->tstream2 && (own ? c->t2_dirty : c->t2_xdirty)) {
+        HIP_TRY(c, hipEventRecord(c->ev_t2, c->tstream2));
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_t2, 0));
+    }
+    if (c->tstream1 && (own ? c->t1_dirty : c->t1_xdirty)) {
+        HIP_TRY(c, hipEventRecord(c->ev_t1, c->tstream1));
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_t1, 0));
+    }
+    if (own) c->t2_dirty = c->t1_dirty = false;
+    else {
+        c->t2_xdirty = c->t1_xdirty = false;
+        if (!(c->bound_in_flight && c->tstream1)) {   // (frames may have run on the ctx's stream itself)
+            HIP_TRY(c, hipEventRecord(c->ev_join, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+        }
+    }
     return FRR_OK;
 }
+int join_tile_streams(frr_ctx *c) { return fence_stream(c, c->stream); }
 
 template <typename T> int ensure(frr_ctx *c, T *&p, size_t &cap, size_t need)
 {
@@ -285,13 +314,17 @@ template <class SET> int gstream_wait_readers(frr_ctx *c, SET &S)
     HIP_TRY(c, hipStreamWaitEvent(gstream_of(c), S.reader_ev, 0));
     return FRR_OK;
 }
-// the second stream waits for everything the caller's stream holds so far (mesh data written by the caller)
+// the stream of the geometry pass about to be issued waits for everything the caller's stream holds so far (mesh data
+// written by the caller before it bound the mesh), once per bind
 int gstream_join(frr_ctx *c)
 {
-    if (!c->fs.on_g || !c->need_join) return FRR_OK;
+    hipStream_t st = gstream_of(c);
+    if (st == c->stream) return FRR_OK;
+    uint32_t &joined = st == c->gstream ? c->joined_g : (st == c->tstream1 ? c->joined_t1 : c->joined_t2);
+    if (joined == c->join_epoch) return FRR_OK;
     HIP_TRY(c, hipEventRecord(c->ev_join, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->gstream, c->ev_join, 0));
-    c->need_join = false;
+    HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    joined = c->join_epoch;
     return FRR_OK;
 }
 // the tile stream waits for what the second stream holds so far (binning -> tile kernel)
@@ -307,7 +340,8 @@ int tstream_wait_gstream(frr_ctx *c)
 int tile_launched(frr_ctx *c, GeomSet &gs, BinSet &bs)
 {
     hipStream_t ts = tstream_of(c);
-    if (ts == c->tstream2) c->t2_dirty = true;
+    if (ts == c->tstream2) c->t2_dirty = c->t2_xdirty = true;
+    if (ts == c->tstream1) c->t1_dirty = c->t1_xdirty = true;
     if (!multi_stream(c)) return FRR_OK;   // everything has run on one stream so far
     HIP_TRY(c, hipEventRecord(gs.reader_ev, ts)); gs.reader_pending = true; gs.reader_stream = ts;
     HIP_TRY(c, hipEventRecord(bs.reader_ev, ts)); bs.reader_pending = true; bs.reader_stream = ts;
@@ -498,7 +532,8 @@ int clear_now(frr_ctx *c, uint32_t packed, float depth)
     const FrameState &f = c->fs;
     const uint32_t n = c->W * c->H, n4 = n / 4;
     hipStream_t ts = tstream_of(c);
-    if (ts == c->tstream2) c->t2_dirty = true;
+    if (ts == c->tstream2) c->t2_dirty = c->t2_xdirty = true;
+    if (ts == c->tstream1) c->t1_dirty = c->t1_xdirty = true;
     {
         ProfScope p(c, KID_CLEAR, ts);
         uint32_t grid = std::min<uint32_t>((n4 + 255) / 256, 2048);
@@ -523,7 +558,8 @@ int settle_targets(frr_ctx *c)
     } else if (f.unowned_debt) {
         RowOwner own = {f.rank, f.world, f.part_blocked ? 1 : 0, 0, 0};
         if (own.blocked) blocked_rows(f.debt_tiles_y, f.rank, f.world, &own.brow0, &own.brow1);
-        if (tstream_of(c) == c->tstream2) c->t2_dirty = true;
+        if (tstream_of(c) == c->tstream2) c->t2_dirty = c->t2_xdirty = true;
+        if (tstream_of(c) == c->tstream1) c->t1_dirty = c->t1_xdirty = true;
         hipLaunchKernelGGL(k_clear_unowned_rows, dim3(c->H), dim3(256), 0, tstream_of(c), (uint32_t *)f.color, (uint32_t *)f.depth,
                            f.tri_id, c->W, c->H, own, f.clear_rgba, f.clear_depth);
         HIP_TRY(c, hipGetLastError());
@@ -553,7 +589,7 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
     // set 0: one set stays hot in the 256 MB Infinity Cache -- two sets of the 1M-triangle frame do not, which costs its
     // tile kernel 4 us).  Measured (profiles/r03_overlap_modes.txt): running beside pays for passes with varyings, whose
     // tile kernel spends long stretches shading (4K textured frame -6 %, a rank of 8 of it -10 %), not for depth-only ones.
-    const bool fif2 = c->frames_in_flight == 2 && own_targets(c);   // consecutive frames already run beside each other, on two streams (frr_clear)
+    const bool fif2 = frames_alternate(c);   // consecutive frames already run beside each other, on two streams (frr_clear)
     const bool on_g = !fif2 && (c->overlap == 1 || (c->overlap == 2 && K > 0));
     const int si = on_g ? (f.gset ^ 1) : (fif2 ? f.tset : 0);
     GeomSet &S = c->gset[si];
@@ -681,7 +717,7 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
     const SpanShape sh = span_shape(c, grid, f.geom_ntris, ps_id);
     const bool segmented = grid <= BIN_LDS_MAX_TILES && !c->bin_atomics && !c->raster_sweep;
     const int q = segmented ? (f.bpar() ^ 1) : 0;   // (the CSR fallback has one set of tile tables: it uses workspace 0 and overlaps nothing)
-    const int bi = !segmented ? 0 : f.on_g ? (f.bset ^ 1) : ((c->frames_in_flight == 2 && own_targets(c)) ? f.tset : 0);
+    const int bi = !segmented ? 0 : f.on_g ? (f.bset ^ 1) : (frames_alternate(c) ? f.tset : 0);
     BinSet &B = c->bset[bi];
     int rc;
     if (!B.bins) {
@@ -927,7 +963,7 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
          hipMalloc((void **)&c->tile_cursor, (c->max_tiles + 1) * 4) == hipSuccess;
     for (GeomSet &S : c->gset) ok = ok && hipEventCreateWithFlags(&S.reader_ev, hipEventDisableTiming) == hipSuccess;
     for (BinSet &B : c->bset) ok = ok && hipEventCreateWithFlags(&B.reader_ev, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->ev_t2, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_t2, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming) == hipSuccess;
     for (auto &e : c->ev_bin) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     if (!ok) { frr_destroy(c); return FRR_ERR_NOMEM; }
@@ -961,6 +997,7 @@ void frr_destroy(frr_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->gstream) (void)hipStreamSynchronize(c->gstream);
     if (c->tstream2) (void)hipStreamSynchronize(c->tstream2);
+    if (c->tstream1) (void)hipStreamSynchronize(c->tstream1);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
@@ -979,11 +1016,13 @@ void frr_destroy(frr_ctx *c)
     for (GeomSet &S : c->gset) if (S.reader_ev) (void)hipEventDestroy(S.reader_ev);
     for (BinSet &B : c->bset) if (B.reader_ev) (void)hipEventDestroy(B.reader_ev);
     if (c->ev_t2) (void)hipEventDestroy(c->ev_t2);
+    if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     for (auto &e : c->ev_bin) if (e) (void)hipEventDestroy(e);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->gstream) (void)hipStreamDestroy(c->gstream);
     if (c->tstream2) (void)hipStreamDestroy(c->tstream2);
+    if (c->tstream1) (void)hipStreamDestroy(c->tstream1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1003,7 +1042,8 @@ int frr_set_option(frr_ctx *c, const char *name, int64_t v)
     else if (n == "bin_atomics") c->bin_atomics = v != 0;
     else if (n == "bin_capacity") { if (v < 0) return fail(c, FRR_ERR_INVALID, "bin_capacity >= 0"); c->bin_cap_init = (size_t)v; }
     else if (n == "fan_capacity") { if (v < 0) return fail(c, FRR_ERR_INVALID, "fan_capacity >= 0"); c->fan_cap_init = (size_t)v; }
-    else if (n == "overlap") { if (v < 0 || v > 2) return fail(c, FRR_ERR_INVALID, "overlap: 0, 1 or 2"); c->overlap = (int)v; c->need_join = true; }
+    else if (n == "overlap") { if (v < 0 || v > 2) return fail(c, FRR_ERR_INVALID, "overlap: 0, 1 or 2"); c->overlap = (int)v; }
+    else if (n == "bound_targets_in_flight") c->bound_in_flight = v != 0;
     else if (n == "frames_in_flight") { if (v != 1 && v != 2) return fail(c, FRR_ERR_INVALID, "frames_in_flight: 1 or 2"); c->frames_in_flight = (int)v; }
     else return fail(c, FRR_ERR_INVALID, "unknown option");
     return FRR_OK;
@@ -1079,7 +1119,7 @@ int frr_bind_targets(frr_ctx *c, void *color, void *depth, void *tri_id)
 {
     if (!c) return FRR_ERR_INVALID;
     { int rc = settle(c); if (rc != FRR_OK) return rc; } // a pending clear belongs to the targets bound when it was issued
-    { int rc = join_tile_streams(c); if (rc != FRR_OK) return rc; }
+    if (!(c->bound_in_flight && !own_targets(c))) { int rc = join_tile_streams(c); if (rc != FRR_OK) return rc; }   // (frames in flight on bound targets: the caller fences)
     c->fs.color = color ? (uint8_t *)color : c->own_color[c->fs.tset];
     c->fs.depth = depth ? (float *)depth : c->own_depth[c->fs.tset];
     c->fs.tri_id = tri_id ? (uint32_t *)tri_id : c->own_tri_id[c->fs.tset];
@@ -1125,7 +1165,7 @@ int frr_mesh_bind_device(frr_ctx *c, const void *dev, uint64_t ntris, int vs_id,
     if (!c || !mesh_out || frr_vs_input_floats(vs_id) < 0 || (ntris && !dev)) return fail(c, FRR_ERR_INVALID, "bad mesh");
     if (ntris >= (1ull << 27)) return fail(c, FRR_ERR_UNSUPPORTED, "more than 2^27 triangles per mesh (order keys: 32 per input triangle)");
     if (((uintptr_t)dev & 15u) != 0) return fail(c, FRR_ERR_INVALID, "mesh pointer must be 16-byte aligned");
-    c->need_join = true;   // the geometry stream has to see what the caller's stream wrote into that memory up to now
+    c->join_epoch += 1;    // the ctx's private streams have to see what the caller's stream wrote into that memory up to now
     return mesh_register(c, (const float *)dev, false, ntris, vs_id, mesh_out);
 }
 int frr_mesh_free(frr_ctx *c, int mesh)
@@ -1253,6 +1293,14 @@ int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
         f.tset = t;
         f.color = c->own_color[t]; f.depth = c->own_depth[t]; f.tri_id = c->own_tri_id[t];
         f.lane = t;    // ... and its own device tables: nothing the two frames' bookkeeping threads write is shared
+    } else if (frames_alternate(c)) {
+        // caller-bound targets, option bound_targets_in_flight: the caller has bound another target set for this frame;
+        // the frame takes the other private stream, workspace set and lane
+        bool ok = (c->tstream2 || hipStreamCreateWithFlags(&c->tstream2, hipStreamNonBlocking) == hipSuccess) &&
+                  (c->tstream1 || hipStreamCreateWithFlags(&c->tstream1, hipStreamNonBlocking) == hipSuccess);
+        if (!ok) return fail(c, FRR_ERR_HIP, "frame streams");
+        f.tset ^= 1;
+        f.lane = f.tset;
     } else {
         f.lane = 0;
     }
@@ -1332,6 +1380,14 @@ int frr_draw(frr_ctx *c, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0
     const int rc = exec_cmd(c, cmd);
     if (rc != FRR_OK) return rc;
     return frr_raster(c, ps_id, x0, x1, y0, y1);
+}
+
+int frr_frame_fence(frr_ctx *c, void *stream)
+{
+    if (!c) return FRR_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rc = settle(c); if (rc != FRR_OK) return rc; }
+    return fence_stream(c, stream ? (hipStream_t)stream : c->stream);
 }
 
 int frr_sync(frr_ctx *c)

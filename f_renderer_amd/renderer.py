@@ -119,7 +119,8 @@ def _options_from_env():
         o["raster_sweep"] = 1
     for var, name in (("FRR_RASTER_NW", "raster_nw"), ("FRR_RASTER_OCC", "raster_occ"), ("FRR_BIN_G", "bin_chunks"),
                       ("FRR_ENT_SLOT", "tile_slot_records"), ("FRR_BIN_CAP", "bin_capacity"), ("FRR_FAN_CAP", "fan_capacity"),
-                      ("FRR_CLIP_QUEUE", "clip_queue"), ("FRR_OVERLAP", "overlap"), ("FRR_FRAMES_IN_FLIGHT", "frames_in_flight")):
+                      ("FRR_CLIP_QUEUE", "clip_queue"), ("FRR_OVERLAP", "overlap"), ("FRR_FRAMES_IN_FLIGHT", "frames_in_flight"),
+                      ("FRR_BOUND_IN_FLIGHT", "bound_targets_in_flight")):
         if e.get(var):
             o[name] = int(e[var])
     if e.get("FRR_CLEAR") == "eager":
@@ -287,6 +288,11 @@ class Renderer:
         wr = width_range or (0, self.width)
         hr = height_range or (0, self.height)
         self._check(self._lib.frr_draw(self._ctx, mesh.id, pixel_shader, wr[0], wr[1], hr[0], hr[1]))
+
+    def frame_fence(self, stream=None):
+        """`stream` (a hipStream_t handle, e.g. torch's stream.cuda_stream; None = the ctx's stream) waits for every frame
+        issued so far -- no host wait (frr_frame_fence; option bound_targets_in_flight)."""
+        self._check(self._lib.frr_frame_fence(self._ctx, C.c_void_p(stream or 0)))
 
     def sync(self):
         self._check(self._lib.frr_sync(self._ctx))

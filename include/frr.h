@@ -222,6 +222,12 @@ int frr_raster(frr_ctx *ctx, int ps_id, int32_t x0, int32_t x1, int32_t y0, int3
  * frr_readback_setup. */
 int frr_draw(frr_ctx *ctx, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1);
 
+/* Stream-side fence, no host wait: `stream` (a hipStream_t of the caller; NULL = the ctx's stream) waits for every frame
+ * issued so far, so that what the caller enqueues on it next sees their targets.  Needed only with option
+ * bound_targets_in_flight (below): without it everything that touches caller-bound targets runs on the ctx's stream anyway.
+ * A draw that needs a larger work list is replayed at the next synchronisation point, not here: callers that consume targets
+ * through fences alone should size the lists once (a warm-up frame followed by frr_sync does). */
+int frr_frame_fence(frr_ctx *ctx, void *stream);
 /* Synchronisation point: waits for everything issued so far (both streams).  Caller-bound targets are defined, and a
  * draw that needed a larger work list has been replayed (FRR_ERR_CAPACITY), when this -- or frr_readback,
  * frr_get_stats, frr_readback_setup, frr_geometry with a count -- returns. */
@@ -248,8 +254,16 @@ int frr_event_elapsed_ms(frr_ctx *ctx, int a, int b, float *ms);
  *   "bin_atomics"             1: global-atomic CSR binning (the path for windows of more than 36,864 tiles)
  *   "bin_capacity"            initial capacity of the (triangle, tile) lists in records (tests of the replay)
  *   "fan_capacity"            initial capacity of the fan space in triangles (the same)
- *   "overlap"                 1 (default): geometry + binning of the next draw run on the ctx's second stream beside the
- *                             tile kernel of the current one; 0: one stream, one kernel after the other
+ *   "frames_in_flight"        2 (default): with the ctx's OWN targets a frame that starts with frr_clear takes the other of two target
+ *                             sets and the other of two streams, so that two frames are in flight (frr_readback / frr_target_ptrs join
+ *                             them; frr_target_ptrs returns the current frame's pointers); 1: one target set, one stream
+ *   "bound_targets_in_flight" 1: the same for caller-bound targets -- every frame runs on one of two PRIVATE streams (none of it on
+ *                             the ctx's stream); the caller binds a different target set for each of two consecutive frames and orders
+ *                             its reads with frr_frame_fence (bench.py's multi-GPU loop).  Default 0: everything that touches
+ *                             caller-bound targets runs on the ctx's stream, in call order
+ *   "overlap"                 frames that are NOT in flight as above: 2 (default) geometry + binning of a pass WITH VARYINGS run on a
+ *                             further private stream beside the previous pass's tile kernel (measured to pay there only); 1: of every
+ *                             pass; 0: one stream, one kernel after the other
  *   "tile_slot_records"       records per tile slot of the near-first copy (tests of its overflow arena)
  *   "clip_queue"              1: clipped inputs beyond four per 256-triangle block are expanded by a second launch
  *                             (k_geom_clip, one wavefront each over the whole chip) instead of by their block; 0: never;

@@ -66,6 +66,7 @@ pub mod ffi {
         pub fn frr_set_uniforms(ctx: *mut frr_ctx, u: *const frr_uniforms) -> c_int;
         pub fn frr_shader_register(ctx: *mut frr_ctx, hip_source: *const c_char, vs_input_floats: c_int, num_varyings: c_int, shader_id: *mut c_int) -> c_int;
         pub fn frr_set_user_uniforms(ctx: *mut frr_ctx, values: *const f32, n: c_int) -> c_int;
+        pub fn frr_frame_fence(ctx: *mut frr_ctx, stream: *mut c_void) -> c_int;
         pub fn frr_partition_rows(y0: i32, y1: i32, rank: c_int, world: c_int, blocked: c_int, band: i32, row0: *mut i32, row1: *mut i32) -> c_int;
         pub fn frr_clear(ctx: *mut frr_ctx, rgba: *const u8, depth: f32) -> c_int;
         pub fn frr_geometry(ctx: *mut frr_ctx, mesh: c_int, ntris_setup: *mut u64) -> c_int;

@@ -11,6 +11,7 @@ shutil.copy(os.path.join(F, "configs.json"), os.path.join(P, f"{TAG}_configs.jso
 shutil.copy(os.path.join(F, "bench_in_flight.json"), os.path.join(P, f"{TAG}_bench_in_flight.json"))
 shutil.copy(os.path.join(F, "bench_serial.json"), os.path.join(P, f"{TAG}_bench_serial.json"))
 shutil.copy(os.path.join(F, "partition_times.json"), os.path.join(P, f"{TAG}_partition_times.json"))
+shutil.copy(os.path.join(F, "partition_times_serial.json"), os.path.join(P, f"{TAG}_partition_times_serial.json"))
 shutil.copy(os.path.join(F, "shapes.log"), os.path.join(P, f"{TAG}_tile_kernel_shapes.txt"))
 shutil.copy(os.path.join(F, "overlap_modes.txt"), os.path.join(P, f"{TAG}_overlap_modes.txt"))
 shutil.copy(os.path.join(F, "frames_in_flight_kernel_timeline.txt"), os.path.join(P, f"{TAG}_frames_in_flight_kernel_timeline.txt"))

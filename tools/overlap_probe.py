@@ -23,14 +23,30 @@ for overlap, fif in modes:
     r.set_count_fragments(False)
     m = r.upload_mesh(cfg["mesh"], getattr(fr, "VS_" + cfg["vs"]))
     ps = getattr(fr, "PS_" + cfg["ps"])
-    for _ in range(10):
+    bound = int(os.environ.get("BOUND", "0"))    # BOUND=1: caller-bound targets (three sets, rotating, as bench.py's multi-GPU loop binds them); 2: + option bound_targets_in_flight
+    if bound:
+        st = torch.cuda.Stream()
+        sets = [(torch.zeros((H, W), dtype=torch.int32, device="cuda"), torch.zeros((H, W), dtype=torch.float32, device="cuda"),
+                 torch.zeros((H, W), dtype=torch.int32, device="cuda")) for _ in range(3)]
+        if bound == 2:
+            r.set_option("bound_targets_in_flight", 1)
+
+    def frame(i):
+        if bound:
+            c_, d_, t_ = sets[i % 3]
+            r.bind_targets(c_.data_ptr(), d_.data_ptr(), t_.data_ptr())
         r.clear(); r.draw(m, ps)
+        if bound == 2:
+            r.frame_fence(st.cuda_stream)       # (where the exchange of the frame would be enqueued)
+
+    for i in range(10):
+        frame(i)
     r.sync()
     t0 = time.perf_counter()
-    for _ in range(N):
-        r.clear(); r.draw(m, ps)
+    for i in range(N):
+        frame(i)
     t1 = time.perf_counter()
     r.sync()
     t2 = time.perf_counter()
-    print(f"{os.environ.get('CFG', 'headline')} part={os.environ.get('PART', '-')} overlap={overlap} frames_in_flight={fif}: host enqueue {(t1 - t0) / N * 1e6:.1f} us/frame, frame {(t2 - t0) / N * 1e6:.1f} us, replays {r.stats()['replays']}", flush=True)
+    print(f"{os.environ.get('CFG', 'headline')} bound={os.environ.get('BOUND', '0')} part={os.environ.get('PART', '-')} overlap={overlap} frames_in_flight={fif}: host enqueue {(t1 - t0) / N * 1e6:.1f} us/frame, frame {(t2 - t0) / N * 1e6:.1f} us, replays {r.stats()['replays']}", flush=True)
     r.close()

@@ -27,7 +27,8 @@ for w in headline cfg4 cfg5; do for p in "" 3,8; do CFG=$w PART=$p N=100 python 
 OVERLAP=2 FIF=2 CFG=headline N=40 rocprofv3 --kernel-trace -d $O/kt_overlap -o kt --output-format csv -- python3 tools/overlap_probe.py > $O/kt_overlap.log 2>&1 || exit 1
 python tools/trace_timeline.py $O/kt_overlap/kt_kernel_trace.csv 4 > $O/frames_in_flight_kernel_timeline.txt || exit 1
 timeout -k 10 600 python tools/run_configs.py --json $O/configs.json > $O/cfg.log 2>&1 || exit 1
-FRR_FRAMES_IN_FLIGHT=1 python tools/partition_times.py --json $O/partition_times.json > $O/part.log 2>&1 || exit 1
+GPU_MAX_HW_QUEUES=8 python tools/partition_times.py --json $O/partition_times.json > $O/part.log 2>&1 || exit 1
+SERIAL=1 python tools/partition_times.py --json $O/partition_times_serial.json > $O/part_serial.log 2>&1 || exit 1
 FRR_FRAMES_IN_FLIGHT=1 FRR_OVERLAP=0 python tools/exp_shapes.py headline cfg4 cfg5 > $O/shapes.log 2>&1 || exit 1
 for w in headline cfg4 cfg5; do FRR_FRAMES_IN_FLIGHT=1 FRR_OVERLAP=0 FRR_LIB=tools/libfrr_dbg.so FRR_DEBUG_TILES=1 FRR_DEBUG_PRINT=1 python tools/tile_timeline.py $w > $O/timeline_$w.log 2>&1 || exit 1; done
 cut -c1-300 $O/bench.json; tail -3 $O/part.log
