@@ -184,6 +184,8 @@ struct frr_ctx {
     uint32_t replays = 0;           // replays since frr_clear (frr_stats.replays)
     bool in_replay = false;
     Counters hc;                    // host copy of the device counters as of the latest finish()
+    uint32_t *host_bad = nullptr;   // host-visible word the device writes a failed command's number to (Counters::host_bad)
+    uint32_t seen_bad = SEQ_NONE;   // its value when the host last looked
     size_t fan_hint = 0;       // fan capacity asked for by a draw that overflowed
     int bin_g = 0;             // option bin_chunks: override the number of binning chunks (dev)
     uint32_t ent_slot_override = 0; // option tile_slot_records: per-tile slot of bins2 in records (tests of the overflow arena)
@@ -846,17 +848,21 @@ int finish(frr_ctx *c)
         }
         c->clip_queue_auto = cbm > (uint32_t)CLIP_QUEUE_AT;
         const uint32_t bad = h.first_bad;
-        if (bad == SEQ_NONE || bad < c->epoch) break;
+        if (c->host_bad) c->seen_bad = *(volatile uint32_t *)c->host_bad;   // (everything has drained: the word is final)
+        if (bad == SEQ_NONE) break;     // (a failure that has been dealt with is reset below)
         size_t i = 0;
         while (i < c->log.size() && c->log[i].seq != bad) ++i;
-        if (i == c->log.size()) return fail(c, FRR_ERR_HIP, "internal error: the failed command is not in the log");
+        // the failed command may belong to a frame whose log is gone (frr_clear came before anybody synchronised): that
+        // frame cannot be replayed any more -- and its targets have been cleared since -- but the lists are grown, so that
+        // the frames from now on fit
+        const bool gone = i == c->log.size();
         if (round == 8) return fail(c, FRR_ERR_CAPACITY, "device work lists still too small after eight replays");
         // grow what was too small
         if (h.overflow & 2u) {
             const uint64_t worst = worst_bins;
             const size_t need = (size_t)(worst + worst / 4 + 1024);
             for (BinSet &B : c->bset) {
-                if (!B.bins && &B != &c->bset[c->log[i].set]) continue;   // (a workspace nobody has used yet is sized when it is)
+                if (!B.bins && (gone || &B != &c->bset[c->log[i].set])) continue;   // (a workspace nobody has used yet is sized when it is)
                 if ((rc = ensure(c, B.bins, B.bin_cap, std::max(need, B.bin_cap))) != FRR_OK) return rc;
                 if ((rc = ensure(c, B.bins2, B.bin2_cap, std::max(need, B.bin2_cap))) != FRR_OK) return rc;
             }
@@ -879,6 +885,7 @@ int finish(frr_ctx *c)
             }
         }
         HIP_TRY(c, hipMemcpy(c->cnt, &h, offsetof(Counters, dbg), hipMemcpyHostToDevice));
+        if (gone) continue;
         // replay
         std::vector<Cmd> todo(c->log.begin() + (ptrdiff_t)i, c->log.end());
         c->log.resize(i);
@@ -972,6 +979,11 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
         // tables of frame 0 (no frame has that number), no failed command
         memset(&c->hc, 0, sizeof c->hc);
         c->hc.first_bad = SEQ_NONE;
+        if (hipHostMalloc((void **)&c->host_bad, 64, hipHostMallocMapped) == hipSuccess) {
+            *c->host_bad = SEQ_NONE;
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, c->host_bad, 0) == hipSuccess) c->hc.host_bad = (uint32_t *)dp;
+        }
         if (hipMemcpy(c->cnt, &c->hc, sizeof(Counters), hipMemcpyHostToDevice) != hipSuccess) { frr_destroy(c); return FRR_ERR_HIP; }
     }
     (void)hipMemsetAsync(c->tile_counts, 0, (c->max_tiles + 1) * 4, c->stream);
@@ -1002,6 +1014,7 @@ void frr_destroy(frr_ctx *c)
     prof_collect(c);
     for (auto &m : c->meshes) if (m.used && m.owned) (void)hipFree((void *)m.dev);
     for (auto &t : c->tex) if (t.dev) (void)hipFree(t.dev);
+    if (c->host_bad) (void)hipHostFree(c->host_bad);
     for (auto &um : c->user_modules) if (um.second.mod) (void)hipModuleUnload(um.second.mod);
     std::vector<void *> ptrs = {c->own_color[0], c->own_depth[0], c->own_tri_id[0], c->own_color[1], c->own_depth[1], c->own_tri_id[1],
                                 c->cnt, c->tile_counts, c->tile_offsets, c->tile_cursor};
@@ -1269,6 +1282,9 @@ int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
     uint32_t packed;
     memcpy(&packed, rgba, 4);
     FrameState &f = c->fs;
+    // Has a command failed since the host last looked (a word the device writes into host memory: no synchronisation)?
+    // Then repair now -- replay the frame if its log is still here, grow the lists either way -- before this frame goes on.
+    if (c->host_bad && *(volatile uint32_t *)c->host_bad != c->seen_bad) { const int rc = finish(c); if (rc != FRR_OK) return rc; }
     // A new frame: the commands logged so far are history.  (One of them may have failed unseen: it and everything after
     // it left the targets untouched, and they are overwritten now.  Device statistics are tagged with the frame number.)
     c->log.clear();

@@ -87,7 +87,8 @@ struct alignas(128) Lane {
 struct Counters {
     uint32_t first_bad;     // see above
     uint32_t overflow;      // bit0 fan capacity, bit1 bin capacity (which list to grow)
-    uint32_t pad0[2];
+    uint32_t *host_bad;     // a word of host-visible memory that receives the number of every failed command: the host looks at
+                            // it (no synchronisation) whenever a new frame starts, and repairs before it goes on
     Lane lane[2];
     // FRR_DEBUG_COUNTERS builds only (tools/debug_counters.py): funnel counters and per-phase wave cycles of the tile
     // kernel, in DBG_COPIES copies (workgroup b adds to copy b % DBG_COPIES: thousands of device atomics on one cache
@@ -120,6 +121,7 @@ __device__ __forceinline__ void seq_fail(Counters *cnt, uint32_t seq, uint32_t e
         if (seen == old) break;
         old = seen;
     }
+    if (cnt->host_bad) __hip_atomic_store(cnt->host_bad, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- slots and order keys --------------------------------------------------------------------------------------
