@@ -467,6 +467,22 @@ constexpr int DIRECT_MAX = 256;  // records of a tile that are culled straight f
 constexpr int DIRECT_STEPS = FRR_DIRECT_STEPS;  // ... in this many steps per wave (at least DIRECT_MIN lanes each)
 constexpr int DIRECT_MIN = 4;
 constexpr int HZ_SEG = 0, HZ_BLK = 128, HZ_QUAD = 144, HZ_C4 = 148, HZ_SIZE = 404;
+// near-first order: buckets of the z bound's key -- its 4 low exponent bits and the top (BKT_LOG2 - 4) mantissa bits
+#ifndef FRR_BKT_LOG2
+#define FRR_BKT_LOG2 6
+#endif
+constexpr int BKT_LOG2 = FRR_BKT_LOG2, BKT_N = 1 << BKT_LOG2, BKT_SHIFT = 27 - BKT_LOG2, BKT_PER = BKT_N / 64;
+__device__ __forceinline__ uint32_t z_bucket(uint32_t zub_key) { return (uint32_t)(BKT_N - 1) - ((zub_key >> BKT_SHIFT) & (uint32_t)(BKT_N - 1)); }
+// exclusive scan of the bucket counters in place (one wave; BKT_PER consecutive buckets per lane), + base
+__device__ __forceinline__ void bucket_scan(uint32_t *s_bkt, int lane, uint32_t base)
+{
+    uint32_t v[BKT_PER], sum = 0u;
+#pragma unroll
+    for (int j = 0; j < BKT_PER; ++j) { v[j] = s_bkt[lane * BKT_PER + j]; sum += v[j]; }
+    uint32_t run = base + wave_incl_scan_dpp(sum) - sum;
+#pragma unroll
+    for (int j = 0; j < BKT_PER; ++j) { s_bkt[lane * BKT_PER + j] = run; run += v[j]; }
+}
 // lane ^ 1 and lane ^ 2 inside each quad of lanes, on the DPP network (no LDS round trip)
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); } // quad_perm [1,0,3,2]
 __device__ __forceinline__ uint32_t dpp_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); } // quad_perm [2,3,0,1]
@@ -534,8 +550,8 @@ template <int NW, int B> struct SpanLds {
     static constexpr int P_END = EXCH + DIRECT_MAX * 16;
     static constexpr int U1 = M_END > P_END ? M_END : P_END;
     static constexpr int HZ = U1;                       // u32[HZ_SIZE] hierarchical z (see hiz_rebuild)
-    static constexpr int BKT = HZ + ((HZ_SIZE + 3) & ~3) * 4; // u32[64]
-    static constexpr int SCAL = BKT + 64 * 4;           // u32[8]: next, dirty, ebase, -, w4[4]
+    static constexpr int BKT = HZ + ((HZ_SIZE + 3) & ~3) * 4; // u32[BKT_N]
+    static constexpr int SCAL = BKT + BKT_N * 4;        // u32[8]: next, dirty, ebase, -, w4[4]
     static constexpr int U8 = SCAL + 8 * 4;             // float[256] (textured shaders)
     static constexpr int bytes(bool textured) { return U8 + (textured ? 256 * 4 : 0); }
 };
@@ -646,7 +662,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
     };
     tile_load_keys(a, c, s_key, ~0ull);
     if (threadIdx.x == 0) { s_next = 0; s_dirty = 1u; s_nanflag = 0u; }
-    if (threadIdx.x < 64) s_bkt[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < BKT_N; i += NW * 64) s_bkt[i] = 0;
     for (int i = threadIdx.x; i < HZ_SIZE; i += NW * 64) s_hz[i] = 0u; // "nothing can be culled" until the first rebuild lands
     __syncthreads();
 
@@ -669,14 +685,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
     if (direct) {
         const bool have = threadIdx.x < nent;
         const uint4 rec = have ? source(threadIdx.x) : make_uint4(0, 0, 0, 0);
-        const uint32_t bkt = COUNT ? 0u : 63u - ((rec.y >> 21) & 63u);
+        const uint32_t bkt = COUNT ? 0u : z_bucket(rec.y);
         if (have) atomicAdd(&s_bkt[bkt], 1u);
         __syncthreads();
-        if (w == 0) {
-            const uint32_t x = s_bkt[lane];
-            const uint32_t incl = wave_incl_scan_dpp(x);
-            s_bkt[lane] = incl - x;
-        }
+        if (w == 0) bucket_scan(s_bkt, lane, 0u);
         __syncthreads();
         uint4 *const exch = s_exch;
         if (have) exch[atomicAdd(&s_bkt[bkt], 1u)] = rec;
@@ -689,7 +701,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         __syncthreads(); // the staging is written again by phase 1b
     } else {
         const bool sorted = !COUNT && nent > 2u * B;
-        auto bucket_of = [&](const uint4 &e) { return sorted ? 63u - ((e.y >> 21) & 63u) : 0u; };
+        auto bucket_of = [&](const uint4 &e) { return sorted ? z_bucket(e.y) : 0u; };
         uint4 ce[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -699,11 +711,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         }
         for (uint32_t e = threadIdx.x + 4u * NW * 64; e < nent; e += NW * 64) atomicAdd(&s_bkt[bucket_of(source(e))], 1u);
         __syncthreads();
-        if (w == 0) {
-            const uint32_t x = s_bkt[lane];
-            const uint32_t incl = wave_incl_scan_dpp(x);
-            s_bkt[lane] = c.beg + incl - x;
-        }
+        if (w == 0) bucket_scan(s_bkt, lane, c.beg);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

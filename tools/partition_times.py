@@ -4,6 +4,7 @@ frame at a time on the ctx's stream), N = 1, 2, 4, 8, on the headline, 4096^2 an
   python tools/partition_times.py [--json profiles/r02_partition_times.json] [headline cfg4 cfg5]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402 (before the library: see tests/conftest.py)
 import f_renderer_amd as fr
 from f_renderer_amd import scenes
 
@@ -12,6 +13,7 @@ out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else N
 if out_json in args:
     args.remove(out_json)
 rows = []
+ST = torch.cuda.Stream()
 for name in (args or ["headline", "cfg4", "cfg5"]):
     cfg = scenes.build_config(name)
     W, H, mesh = cfg["W"], cfg["H"], cfg["mesh"]
@@ -26,8 +28,7 @@ for name in (args or ["headline", "cfg4", "cfg5"]):
     r.set_count_fragments(False)
     # as bench.py's multi-GPU loop renders: caller-bound target sets (three, rotating), two frames in flight on them
     # (option bound_targets_in_flight), the frame's exchange fenced on the caller's stream (no exchange here: one GPU)
-    import torch
-    st = torch.cuda.Stream()
+    st = ST   # (one caller stream for every workload: a process's HIP streams share few hardware queues)
     sets = [(torch.zeros((H, W), dtype=torch.int32, device="cuda"), torch.zeros((H, W), dtype=torch.float32, device="cuda"),
              torch.zeros((H, W), dtype=torch.int32, device="cuda")) for _ in range(3)]
     r.set_option("bound_targets_in_flight", 0 if os.environ.get("SERIAL") else 1)
@@ -51,6 +52,8 @@ for name in (args or ["headline", "cfg4", "cfg5"]):
                 frame(i)
             r.sync()
             per_rank.append((time.perf_counter() - t0) / K * 1e6)
+            if os.environ.get("VERBOSE"):
+                print("   rank", rank, "of", N, round(per_rank[-1], 1), "us, replays", r.stats()["replays"], flush=True)
         row = dict(workload=name, width=W, height=H, N=N, max_us=round(max(per_rank), 1), mean_us=round(sum(per_rank) / N, 1),
                    per_rank_us=[round(x, 1) for x in per_rank])
         rows.append(row)
