@@ -66,6 +66,29 @@ const UserShader *user_shader(int id)
     const int i = id - FRR_SHADER_USER_BASE;
     return (i >= 0 && i < (int)g_shaders.size()) ? g_shaders[(size_t)i] : nullptr;
 }
+// The library's private streams are recycled across contexts (per device): a process's HIP streams are mapped onto a handful
+// of hardware queues in creation order, and a ctx created after others must not end up with its two frame streams -- or a frame
+// stream and the caller's -- on one queue (two streams that share a queue run nothing beside each other).  Recycling keeps the
+// queues a process's contexts use the same few from the first context to the last.
+std::mutex g_stream_mu;
+std::map<int, std::vector<hipStream_t>> g_stream_pool;
+hipError_t acquire_stream(int device, hipStream_t *out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        std::vector<hipStream_t> &v = g_stream_pool[device];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void release_stream(int device, hipStream_t st)
+{
+    if (!st) return;
+    (void)hipStreamSynchronize(st);
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_stream_pool[device].push_back(st);
+}
+
 struct UserModule {
     hipModule_t mod = nullptr;
     hipFunction_t geom = nullptr, clip = nullptr, span[2][6] = {};
@@ -627,7 +650,7 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
     if (on_g && !c->gstream) {
         // created on first use: a process maps its HIP streams onto a handful of hardware queues, and two streams that
         // share one run nothing beside each other -- a ctx that never needs this stream does not take a queue for it
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking));
+        HIP_TRY(c, acquire_stream(c->device, &c->gstream));
     }
     if (on_g != f.on_g) {
         // this pass changes streams: it follows the previous pass's geometry + binning (tri_base, fan cursors)
@@ -960,7 +983,7 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     frr_ctx *c = new frr_ctx();
     c->device = device; c->W = width; c->H = height;
     if (stream) c->stream = (hipStream_t)stream;
-    else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FRR_ERR_HIP; } c->own_stream = true; }
+    else { if (acquire_stream(device, &c->stream) != hipSuccess) { delete c; return FRR_ERR_HIP; } c->own_stream = true; }
     const size_t npx = (size_t)width * height;
     bool ok = hipMalloc((void **)&c->own_color[0], npx * 4) == hipSuccess && hipMalloc((void **)&c->own_depth[0], npx * 4) == hipSuccess &&
               hipMalloc((void **)&c->own_tri_id[0], npx * 4) == hipSuccess && hipMalloc((void **)&c->cnt, sizeof(Counters)) == hipSuccess;
@@ -1033,10 +1056,11 @@ void frr_destroy(frr_ctx *c)
     for (auto &e : c->ev_bin) if (e) (void)hipEventDestroy(e);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
-    if (c->gstream) (void)hipStreamDestroy(c->gstream);
-    if (c->tstream2) (void)hipStreamDestroy(c->tstream2);
-    if (c->tstream1) (void)hipStreamDestroy(c->tstream1);
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    // (back to the pool in the reverse order of their typical acquisition, so that the next ctx gets them in the same roles)
+    release_stream(c->device, c->gstream);
+    release_stream(c->device, c->tstream1);
+    release_stream(c->device, c->tstream2);
+    if (c->own_stream) release_stream(c->device, c->stream);
     delete c;
 }
 
@@ -1303,7 +1327,7 @@ int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
             const size_t npx = (size_t)c->W * c->H;
             bool ok = hipMalloc((void **)&c->own_color[t], npx * 4) == hipSuccess && hipMalloc((void **)&c->own_depth[t], npx * 4) == hipSuccess &&
                       hipMalloc((void **)&c->own_tri_id[t], npx * 4) == hipSuccess;
-            ok = ok && (c->tstream2 || hipStreamCreateWithFlags(&c->tstream2, hipStreamNonBlocking) == hipSuccess);
+            ok = ok && (c->tstream2 || acquire_stream(c->device, &c->tstream2) == hipSuccess);
             if (!ok) return fail(c, FRR_ERR_NOMEM, "second target set");
         }
         f.tset = t;
@@ -1312,8 +1336,8 @@ int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
     } else if (frames_alternate(c)) {
         // caller-bound targets, option bound_targets_in_flight: the caller has bound another target set for this frame;
         // the frame takes the other private stream, workspace set and lane
-        bool ok = (c->tstream2 || hipStreamCreateWithFlags(&c->tstream2, hipStreamNonBlocking) == hipSuccess) &&
-                  (c->tstream1 || hipStreamCreateWithFlags(&c->tstream1, hipStreamNonBlocking) == hipSuccess);
+        bool ok = (c->tstream2 || acquire_stream(c->device, &c->tstream2) == hipSuccess) &&
+                  (c->tstream1 || acquire_stream(c->device, &c->tstream1) == hipSuccess);
         if (!ok) return fail(c, FRR_ERR_HIP, "frame streams");
         f.tset ^= 1;
         f.lane = f.tset;
