@@ -76,6 +76,7 @@ def test_own_targets_two_frames_in_flight(oracle, overlap):
     sc = _scenes(oracle, W, H)
     st = torch.cuda.Stream()
     r = fr.Renderer(W, H, stream=st.cuda_stream)
+    r.set_option("frames_in_flight", 2)           # (the default; the suite may run with FRR_FRAMES_IN_FLIGHT=1 in the environment)
     r.set_option("overlap", overlap)
     meshes = [r.upload_mesh(t, fr.VS_CLIP_COLOR) for t, _ in sc]
     ptrs = set()
