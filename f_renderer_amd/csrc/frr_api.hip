@@ -110,6 +110,7 @@ struct GeomSet {
     uint2 *clipq = nullptr; size_t clipq_cap = 0;               // [input triangles] the clip kernel's queue (GeomArgs::clipq)
     hipEvent_t reader_ev = nullptr; bool reader_pending = false; // fires when the latest tile kernel that reads this set is done
     hipStream_t reader_stream = nullptr;                         // ... on this stream
+    bool reader_recorded = false;                                // the event was recorded right behind that kernel
 };
 struct BinSet {
     uint4 *bins = nullptr; size_t bin_cap = 0;   // 16-byte cull records, one per (triangle, tile) pair
@@ -117,6 +118,7 @@ struct BinSet {
     uint32_t *bin_matrix = nullptr; size_t bin_matrix_cap = 0; // [G][ntiles] per-chunk tile histograms
     hipEvent_t reader_ev = nullptr; bool reader_pending = false;
     hipStream_t reader_stream = nullptr;
+    bool reader_recorded = false;
 };
 
 struct GeomFilter { bool active; int32_t y0, y1; int rank, world; bool blocked; };
@@ -336,6 +338,9 @@ template <class SET> int gstream_wait_readers(frr_ctx *c, SET &S)
     if (!S.reader_pending) return FRR_OK;
     S.reader_pending = false;
     if (S.reader_stream == gstream_of(c)) return FRR_OK;   // same stream: already in order
+    // (the event may not have been recorded at the launch: then now, after whatever else the reader's stream has been given
+    // since -- more than needed, and right for the rare change of pattern this serves)
+    if (!S.reader_recorded) HIP_TRY(c, hipEventRecord(S.reader_ev, S.reader_stream));
     HIP_TRY(c, hipStreamWaitEvent(gstream_of(c), S.reader_ev, 0));
     return FRR_OK;
 }
@@ -368,8 +373,12 @@ int tile_launched(frr_ctx *c, GeomSet &gs, BinSet &bs)
     if (ts == c->tstream2) c->t2_dirty = c->t2_xdirty = true;
     if (ts == c->tstream1) c->t1_dirty = c->t1_xdirty = true;
     if (!multi_stream(c)) return FRR_OK;   // everything has run on one stream so far
-    HIP_TRY(c, hipEventRecord(gs.reader_ev, ts)); gs.reader_pending = true; gs.reader_stream = ts;
-    HIP_TRY(c, hipEventRecord(bs.reader_ev, ts)); bs.reader_pending = true; bs.reader_stream = ts;
+    // Frames in flight give every frame stream its own workspace sets: the next writer of a set is on the reader's stream, and
+    // no event is needed (should the pattern change, gstream_wait_readers records one late).  With geometry + binning on the
+    // second stream the event is what lets that stream run beside the NEXT tile kernel: recorded right here.
+    const bool eager = c->g_used;
+    gs.reader_pending = bs.reader_pending = true; gs.reader_stream = bs.reader_stream = ts; gs.reader_recorded = bs.reader_recorded = eager;
+    if (eager) { HIP_TRY(c, hipEventRecord(gs.reader_ev, ts)); HIP_TRY(c, hipEventRecord(bs.reader_ev, ts)); }
     return FRR_OK;
 }
 
