@@ -20,6 +20,9 @@ HIPCC_FLAGS = [
     # bit-exactness contract with the reference's Rust fp32 semantics: no FMA contraction,
     # no fast-math; IEEE div/sqrt and preserved denormals are hipcc defaults and stay on.
     "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+    # no SLP packing: a v_pk_* f32 instruction issues in the time of its two scalar halves on gfx950 and the register
+    # shuffles that pair the operands come on top (tools/valu_rates.hip; -10 % VALU time in the shaded resolve)
+    "-fno-slp-vectorize",
     # user shaders (frr_shader_register): the device headers' text is embedded (.incbin) and compiled at run time by hiprtc
     "-DFRR_CSRC_DIR=\"%s\"" % os.path.join(_HERE, "csrc"), "-L/opt/rocm/lib", "-lhiprtc", "-Wl,-rpath,/opt/rocm/lib",
 ]

@@ -1281,8 +1281,8 @@ int frr_shader_register(frr_ctx *c, const char *hip_source, int vs_input_floats,
         for (int sh = 0; sh < 6; ++sh)
             exprs.push_back("frr::k_raster_span<" + Ks + ", " + U + ", " + (cnt ? "true" : "false") + ", " + std::to_string(kSpanShapes[sh][0]) + ", " + std::to_string(kSpanShapes[sh][1]) + ">");
     for (const std::string &e : exprs) (void)hiprtcAddNameExpression(prog, e.c_str());
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function"};
-    const hiprtcResult res = hiprtcCompileProgram(prog, 6, opts);
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wno-unused-function"};
+    const hiprtcResult res = hiprtcCompileProgram(prog, 7, opts);
     if (res != HIPRTC_SUCCESS) {
         size_t n = 0;
         (void)hiprtcGetProgramLogSize(prog, &n);

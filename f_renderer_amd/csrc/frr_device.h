@@ -296,7 +296,7 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 }
 __device__ __forceinline__ void normalize3(float &x, float &y, float &z)
 {
-    float r = recip_exact(sqrtf(dot3(x, y, z, x, y, z))); // Vec3::normalize = self * length_recip(); == 1.0f / sqrt, bit for bit
+    float r = rsqrt_exact(dot3(x, y, z, x, y, z)); // Vec3::normalize = self * length_recip(); == 1.0f / sqrtf, bit for bit
     x = x * r; y = y * r; z = z * r;
 }
 __device__ __forceinline__ void mat4_mul_vec4(const float *m, float x, float y, float z, float w, float o[4])

@@ -83,17 +83,48 @@ FRR_HD float zkey_decode(uint32_t k)
 // v_rcp_f32 is a 1-ulp estimate y; one Newton step written with exact residuals, y + y*(1 - s*y),
 // lands on the IEEE quotient for every s in [2^-64, 2^64] -- verified EXHAUSTIVELY against the
 // compiler's IEEE division on the device (frr_debug_rcp_check, tests/test_gpu_parity.py); operands
-// outside that range (and NaN/inf/0) take the IEEE division.
+// outside that range (and NaN/inf/0) take the IEEE division.  The three instructions run unconditionally and the
+// division only if SOME lane of the wave needs it (one scalar branch that is almost never taken, instead of a
+// divergent one around each path).
+FRR_HD bool recip_fast_range(float s)
+{
+    const uint32_t e = (f2u(s) >> 23) & 0x1FFu; // sign | exponent
+    return e - 63u < 129u;                      // positive, 2^-64 <= s < 2^65
+}
 FRR_HD float recip_exact(float s)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t e = (f2u(s) >> 23) & 0x1FFu; // sign | exponent
-    if (e - 63u < 129u) {                       // positive, 2^-64 <= s < 2^65
-        const float y = __builtin_amdgcn_rcpf(s);
-        return __builtin_fmaf(y, __builtin_fmaf(-s, y, 1.0f), y);
-    }
-#endif
+    const bool in = recip_fast_range(s);
+    const float y = __builtin_amdgcn_rcpf(s);
+    float r = __builtin_fmaf(y, __builtin_fmaf(-s, y, 1.0f), y);
+    if (__builtin_amdgcn_ballot_w64(!in) != 0ull) r = in ? r : 1.0f / s;
+    return r;
+#else
     return 1.0f / s;
+#endif
+}
+
+// 1.0f / sqrtf(d) as the reference rounds it (two correctly rounded operations: Vec3::length_recip), for the
+// normalisations of the shaders.  For d in [2^-64, 2^65) the square root needs none of the scaling the compiler's IEEE
+// sqrtf carries for tiny operands: v_sqrt_f32 is a 1-ulp estimate, and the two neighbours are tried with exact
+// residuals exactly as the compiler's own expansion does; the root then lies in recip_exact's verified range.
+// Everything else takes the IEEE operations (again only if some lane of the wave needs them).
+FRR_HD float rsqrt_exact(float d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool in = recip_fast_range(d);
+    float s = __builtin_amdgcn_sqrtf(d);
+    const float sd = u2f(f2u(s) - 1u), su = u2f(f2u(s) + 1u);
+    const float rd = __builtin_fmaf(-sd, s, d), ru = __builtin_fmaf(-su, s, d);
+    s = rd <= 0.0f ? sd : s;
+    s = ru > 0.0f ? su : s;
+    const float y = __builtin_amdgcn_rcpf(s);
+    float r = __builtin_fmaf(y, __builtin_fmaf(-s, y, 1.0f), y);
+    if (__builtin_amdgcn_ballot_w64(!in) != 0ull) r = in ? r : 1.0f / sqrtf(d);
+    return r;
+#else
+    return 1.0f / sqrtf(d);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

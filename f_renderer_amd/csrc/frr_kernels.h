@@ -951,7 +951,8 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
 namespace frr {
 
 // ---- debug --------------------------------------------------------------------------------
-// recip_exact against the IEEE division over a range of bit patterns: number of differing results, first offender
+// recip_exact against the IEEE division, and rsqrt_exact against 1.0f / sqrtf, over a range of bit patterns: number of
+// differing results, first offender
 __global__ __launch_bounds__(256) void k_debug_rcp(uint32_t lo, uint32_t hi, unsigned long long *bad, uint32_t *first)
 {
     unsigned long long n = 0;
@@ -959,6 +960,8 @@ __global__ __launch_bounds__(256) void k_debug_rcp(uint32_t lo, uint32_t hi, uns
         const float s = u2f((uint32_t)b);
         const float q = 1.0f / s, r = recip_exact(s);
         if (f2u(q) != f2u(r) && !(q != q && r != r)) { ++n; atomicMin(first, (uint32_t)b); }
+        const float q2 = 1.0f / sqrtf(s), r2 = rsqrt_exact(s);
+        if (f2u(q2) != f2u(r2) && !(q2 != q2 && r2 != r2)) { ++n; atomicMin(first, (uint32_t)b); }
     }
     if (n) atomicAdd(bad, n);
 }

@@ -401,8 +401,9 @@ __device__ __forceinline__ SegPos seg_locate(uint32_t h_lo, uint32_t h_hi, uint3
     const uint32_t m_lo = h_lo & le_lo, m_hi = h_hi & le_hi;
     SegPos s;
     s.k = __popc(m_lo) + __popc(m_hi);
-    const int hp = m_hi ? 63 - __clz((int)m_hi) : (m_lo ? 31 - __clz((int)m_lo) : -1);
-    s.off = hp >= 0 ? lane - hp : lane + carry;
+    // leading zeros of the 64-bit mask (64 if it is empty), straight-line code
+    const int z = __clzll(((unsigned long long)m_hi << 32) | (unsigned long long)m_lo);
+    s.off = z < 64 ? lane - 63 + z : lane + carry;
     return s;
 }
 // scalar bookkeeping for the next window: heads consumed, and how far into the open segment we are
@@ -503,7 +504,7 @@ __device__ __forceinline__ void hiz_rebuild(const unsigned long long *s_key, uin
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        if ((lane & 1) == 0) hz[HZ_C4 + 32 * k + (lane >> 1)] = c4[k];
+        if ((lane & 1) == 0) hz[HZ_C4 + 32 * k + (lane >> 1)] = c4[k] >> 1;
         if ((lane & 3) == 0) hz[HZ_SEG + 16 * k + (lane >> 2)] = sg[k];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -893,11 +894,18 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             if (len > 0) {
                 const uint4 ca = *reinterpret_cast<const uint4 *>(&s_hz[HZ_C4 + yl * 8]);
                 const uint4 cb = *reinterpret_cast<const uint4 *>(&s_hz[HZ_C4 + yl * 8 + 4]);
-                uint32_t pm = (uint32_t)!(zu < ca.x) | ((uint32_t)!(zu < ca.y) << 1) | ((uint32_t)!(zu < ca.z) << 2) | ((uint32_t)!(zu < ca.w) << 3) |
-                              ((uint32_t)!(zu < cb.x) << 4) | ((uint32_t)!(zu < cb.y) << 5) | ((uint32_t)!(zu < cb.z) << 6) | ((uint32_t)!(zu < cb.w) << 7);
+                // the cells hold (minimum >> 1): "zu >> 1 below it" implies zu < minimum (conservative in the last bit), and
+                // with both operands below 2^31 the sign of the difference is the comparison -- a subtraction and a funnel
+                // shift per cell instead of a compare and a select.  Bit i of cm: the bound cannot win in cell i.
+                const uint32_t zh = zu >> 1;
+                uint32_t cm = 0u;
+                cm = __builtin_amdgcn_alignbit(cm, zh - cb.w, 31); cm = __builtin_amdgcn_alignbit(cm, zh - cb.z, 31);
+                cm = __builtin_amdgcn_alignbit(cm, zh - cb.y, 31); cm = __builtin_amdgcn_alignbit(cm, zh - cb.x, 31);
+                cm = __builtin_amdgcn_alignbit(cm, zh - ca.w, 31); cm = __builtin_amdgcn_alignbit(cm, zh - ca.z, 31);
+                cm = __builtin_amdgcn_alignbit(cm, zh - ca.y, 31); cm = __builtin_amdgcn_alignbit(cm, zh - ca.x, 31);
                 const int xr = xl + len - 1;
                 const int c0 = xl >> 2, c1 = xr >> 2;
-                pm &= (2u << c1) - (1u << c0);
+                const uint32_t pm = ~cm & ((2u << c1) - (1u << c0));
                 if (pm == 0u) {
                     len = 0;
                 } else {

@@ -303,8 +303,8 @@ int frr_debug_gather_calib(frr_ctx *ctx, uint32_t log2_records);
 /* device wave64 inclusive prefix sum (DPP) of 64 values, for tests */
 int frr_debug_scan64(frr_ctx *ctx, const uint32_t *in, uint32_t *out);
 /* the three-instruction reciprocal of the fragment loop (frr_exact.h: recip_exact) against the IEEE
- * division for every f32 bit pattern in [lo_bits, hi_bits): number of differing results and the
- * smallest offending pattern (0xFFFFFFFF if none). */
+ * division, and the shaders' 1/sqrt (rsqrt_exact) against 1.0f / sqrtf, for every f32 bit pattern in
+ * [lo_bits, hi_bits): number of differing results and the smallest offending pattern (0xFFFFFFFF if none). */
 int frr_debug_rcp_check(frr_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches, uint32_t *first_bad);
 
 #ifdef __cplusplus

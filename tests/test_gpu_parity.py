@@ -346,7 +346,9 @@ def test_sweep_kernel_still_exact(oracle, mode, monkeypatch):
 
 def test_fast_reciprocal_is_ieee_exact_for_every_float():
     """recip_exact (v_rcp_f32 + one exact-residual Newton step, IEEE division outside [2^-64, 2^65)) is
-    what the fragment loop uses for `1.0 / s` (renderer.rs:356): all 2^32 bit patterns on the device."""
+    what the fragment loop uses for `1.0 / s` (renderer.rs:356), and rsqrt_exact (v_sqrt_f32 + the neighbour test with
+    exact residuals, then the same reciprocal) is the shaders' `normalize` (phong.rs:136-141): both against the
+    compiler's IEEE operations for all 2^32 bit patterns on the device."""
     import f_renderer_amd as fr
     r = fr.Renderer(64, 64)
     total = 0
