@@ -733,6 +733,7 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
     a.blocked = (f.part_blocked && f.world > 1) ? 1 : 0; a.brow0 = a.brow1 = 0;
     if (a.blocked) blocked_rows(a.tiles_y, a.rank, a.world, &a.brow0, &a.brow1);
     a.recs = S.recs; a.vary = S.vary; a.pbox = S.pbox; a.bcount = S.bcount;
+    a.tinfo = S.tinfo; a.fanbase = S.fanbase; a.fan_okey = S.fan_okey; a.block_prefix = S.block_prefix; a.ntris_draw = (uint32_t)f.geom_ntris;
     a.tile_counts = c->tile_counts; a.tile_offsets = c->tile_offsets; a.tile_cursor = c->tile_cursor;
     a.gpar = f.gpar(); a.lane = f.lane; a.bpar = 0; a.seq = cmd.seq; a.epoch = c->epoch; a.frame_no = f.frame_no; a.geom_seq = f.geom_seq;
     const uint32_t ntiles = (uint32_t)a.tiles_x * a.tiles_y;

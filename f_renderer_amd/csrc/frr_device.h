@@ -191,6 +191,11 @@ struct RasterArgs {
     const float *vary;
     const uint4 *pbox;                // see GeomArgs::pbox
     const uint32_t *bcount;           // see GeomArgs::bcount
+    // the rasterized geometry pass's id tables (GeomArgs / GeomTab hold the same pointers; as kernel arguments the tile
+    // kernel reads them from the constant kernarg segment whenever it needs them -- no dependent global load in front
+    // of every triangle-id lookup, and nothing to keep in registers)
+    const uint32_t *tinfo, *fanbase, *fan_okey, *block_prefix;
+    uint32_t ntris_draw;              // input triangles of that pass (= its first fan slot)
     uint32_t *tile_counts;            // [ntiles]
     uint32_t *tile_offsets;           // [ntiles+1]
     uint32_t *tile_cursor;            // [ntiles]

@@ -32,48 +32,49 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 }
 
 // ---- order keys <-> slots <-> emission indices of the current draw (frr_device.h: slots and order keys) -------------
+// (the tables come from the kernel arguments, RasterArgs::tinfo ...; only tri_base lives in the device-side GeomTab)
 // low half of a pixel key for the triangle at `slot`: order key + 1 (0 = "what was there before this draw")
-__device__ __forceinline__ uint32_t order_id(const GeomTab *cnt, uint32_t slot)
+__device__ __forceinline__ uint32_t order_id(const RasterArgs &a, uint32_t slot)
 {
-    const uint32_t nt = cnt->ntris_draw;
-    return 1u + (slot < nt ? slot << FAN_BITS : cnt->fan_okey[slot - nt]);
+    const uint32_t nt = a.ntris_draw;
+    return 1u + (slot < nt ? slot << FAN_BITS : a.fan_okey[slot - nt]);
 }
 // the slot a winning id of THIS draw names, and the reference's emission index of that triangle within the frame
-__device__ __forceinline__ uint32_t id_slot(const GeomTab *cnt, uint32_t id)
+__device__ __forceinline__ uint32_t id_slot(const RasterArgs &a, uint32_t id)
 {
     const uint32_t okl = id - 1u, t = okl >> FAN_BITS, f = okl & ((1u << FAN_BITS) - 1u);
-    return f ? cnt->ntris_draw + cnt->fanbase[t] + (f - 1u) : t;
+    return f ? a.ntris_draw + a.fanbase[t] + (f - 1u) : t;
 }
-__device__ __forceinline__ uint32_t id_emission(const GeomTab *cnt, uint32_t id)
+__device__ __forceinline__ uint32_t id_emission(const RasterArgs &a, uint32_t tri_base, uint32_t id)
 {
     const uint32_t okl = id - 1u, t = okl >> FAN_BITS, f = okl & ((1u << FAN_BITS) - 1u);
-    return cnt->tri_base + cnt->block_prefix[t / GEOM_BLOCK] + (cnt->tinfo[t] >> FAN_BITS) + (f ? f - 1u : 0u);
+    return tri_base + a.block_prefix[t / GEOM_BLOCK] + (a.tinfo[t] >> FAN_BITS) + (f ? f - 1u : 0u);
 }
 
 // Depth-only draws keep  emission index (within the draw) + 1  in their pixel keys instead of the order key: it is
 // just as monotone, the lookups below are then paid once per surviving triangle of a tile instead of once per pixel,
 // and the resolve adds tri_base.  (Shaded draws need the winner's SLOT per pixel, which only the order key gives.)
-__device__ __forceinline__ uint32_t emission_id(const GeomTab *cnt, uint32_t slot)
+__device__ __forceinline__ uint32_t emission_id(const RasterArgs &a, uint32_t slot)
 {
-    const uint32_t nt = cnt->ntris_draw;
+    const uint32_t nt = a.ntris_draw;
     uint32_t t = slot, q = 0u;
-    if (slot >= nt) { const uint32_t ok = cnt->fan_okey[slot - nt]; t = ok >> FAN_BITS; q = (ok & ((1u << FAN_BITS) - 1u)) - 1u; }
-    return 1u + cnt->block_prefix[t / GEOM_BLOCK] + (cnt->tinfo[t] >> FAN_BITS) + q;
+    if (slot >= nt) { const uint32_t ok = a.fan_okey[slot - nt]; t = ok >> FAN_BITS; q = (ok & ((1u << FAN_BITS) - 1u)) - 1u; }
+    return 1u + a.block_prefix[t / GEOM_BLOCK] + (a.tinfo[t] >> FAN_BITS) + q;
 }
 // the slot of the triangle with emission index e (within the draw): two binary searches; only the depth-only resolve's
 // rare re-evaluation (-0.0 / NaN depths) needs it
-__device__ __forceinline__ uint32_t slot_of_emission(const GeomTab *cnt, uint32_t e)
+__device__ __forceinline__ uint32_t slot_of_emission(const RasterArgs &cnt, uint32_t e)
 {
-    const uint32_t nt = cnt->ntris_draw, nb = (nt + GEOM_BLOCK - 1) / GEOM_BLOCK;
+    const uint32_t nt = cnt.ntris_draw, nb = (nt + GEOM_BLOCK - 1) / GEOM_BLOCK;
     uint32_t lo = 0, hi = nb;                       // last block whose prefix <= e
-    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (cnt->block_prefix[mid] <= e) lo = mid; else hi = mid; }
-    const uint32_t r = e - cnt->block_prefix[lo];
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (cnt.block_prefix[mid] <= e) lo = mid; else hi = mid; }
+    const uint32_t r = e - cnt.block_prefix[lo];
     uint32_t a = lo * GEOM_BLOCK, b = min(nt, a + GEOM_BLOCK); // last input of the block whose offset <= r and that emits anything
-    while (b - a > 1u) { const uint32_t mid = (a + b) >> 1; if ((cnt->tinfo[mid] >> FAN_BITS) <= r) a = mid; else b = mid; }
+    while (b - a > 1u) { const uint32_t mid = (a + b) >> 1; if ((cnt.tinfo[mid] >> FAN_BITS) <= r) a = mid; else b = mid; }
     // (inputs that emit nothing share their successor's offset: step back to the one that covers r)
-    while ((cnt->tinfo[a] & ((1u << FAN_BITS) - 1u)) == 0u && a > lo * GEOM_BLOCK) --a;
-    const uint32_t ti = cnt->tinfo[a], n = ti & ((1u << FAN_BITS) - 1u), q = r - (ti >> FAN_BITS);
-    return n == 1u ? a : nt + cnt->fanbase[a] + q;
+    while ((cnt.tinfo[a] & ((1u << FAN_BITS) - 1u)) == 0u && a > lo * GEOM_BLOCK) --a;
+    const uint32_t ti = cnt.tinfo[a], n = ti & ((1u << FAN_BITS) - 1u), q = r - (ti >> FAN_BITS);
+    return n == 1u ? a : nt + cnt.fanbase[a] + q;
 }
 
 __device__ __forceinline__ const GeomTab *gtab_of(const RasterArgs &a) { return &a.cnt->lane[a.lane].gtab[a.gpar]; }
@@ -145,6 +146,7 @@ template <int K, int PS>
 __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUniforms &u, const TileCtx &c,
                                              const unsigned long long *s_key, const float *u8lut = nullptr)
 {
+    const uint32_t tri_base = gtab_of(a)->tri_base;
     for (int i = threadIdx.x; i < TILE_PX; i += (int)blockDim.x) {
         const int x = i & (TILE - 1), y = i >> 5;
         if (x >= c.tw || y >= c.th) continue;
@@ -155,7 +157,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
             if (id == 0u) { a.depth[pi] = a.clear_depth; a.tri_id[pi] = ~0u; }
         }
         if (id == 0u) continue; // existing depth won (or nothing covered this pixel)
-        const uint32_t t = id_slot(gtab_of(a), id);
+        const uint32_t t = id_slot(a, id);
         if constexpr (PS == FRR_PS_DEPTH) {
             // depth only: the z key is an invertible image of rhw except that it merges -0.0 with +0.0
             // (and NaNs are not ordered): those two cases are re-evaluated below, everything else is decoded
@@ -163,7 +165,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
             if (dz != 0.0f && dz == dz) {
                 const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
                 a.depth[di] = dz;                                                   // :366
-                a.tri_id[di] = id_emission(gtab_of(a), id);
+                a.tri_id[di] = id_emission(a, tri_base, id);
                 continue;
             }
         }
@@ -174,7 +176,7 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
         Frag f = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), r0, r1, r2, cx, cy);
         const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
         a.depth[di] = f.rhw;                                                    // :366
-        a.tri_id[di] = id_emission(gtab_of(a), id);
+        a.tri_id[di] = id_emission(a, tri_base, id);
         if constexpr (PS != FRR_PS_DEPTH) {
             const float w = recip_exact(f.rhw != 0.0f ? f.rhw : 1.0f);          // :368 (== 1.0f / x, bit for bit)
             const float c0 = r0 * f.a * w, c1 = r1 * f.b * w, c2 = r2 * f.c * w; // :370-372
@@ -213,7 +215,7 @@ __device__ __forceinline__ void tile_resolve_depth4(const RasterArgs &a, const T
             won[i] = id[i] != 0u && x + i < c.tw;      // (pixels of a partial tile beyond the window hold all-ones keys)
             float dz = zkey_decode(zk[i]);
             if (won[i] && !(dz != 0.0f && dz == dz)) { // -0.0 merged with +0.0, or NaN: the reference arithmetic decides
-                const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + slot_of_emission(gtab_of(a), id[i] - 1u));
+                const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + slot_of_emission(a, id[i] - 1u));
                 const uint4 q1 = rp[1], q2 = rp[2], q3 = rp[3];
                 dz = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y), u2f(q3.z),
                                c.ax0 + x + i, c.ay0 + y).rhw;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
     uint32_t n_cov = 0, n_nan = 0;
     for (uint32_t e = c.beg + wave; e < c.end; e += 4) {
         const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e].x);
-        sweep_triangle(a, c, t, order_id(gtab_of(a), t), lane, s_key, n_cov, n_nan, &s_nanflag);
+        sweep_triangle(a, c, t, order_id(a, t), lane, s_key, n_cov, n_nan, &s_nanflag);
     }
     if (lane == 0 && n_cov) atomicAdd(&a.cnt->lane[a.lane].gtab[a.gpar].frag_covered, (unsigned long long)n_cov);
     if (n_nan) atomicAdd(&a.cnt->lane[a.lane].gtab[a.gpar].frag_nan, (unsigned long long)n_nan);
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a, DevUniforms u)
         __syncthreads();
         for (uint32_t e = c.beg + wave; e < c.end; e += 4) {
             const uint32_t t = __builtin_amdgcn_readfirstlane(a.bins[e].x);
-            sweep_triangle<true>(a, c, t, order_id(gtab_of(a), t), lane, s_key, n_cov, n_nan, nullptr, s_nanL);
+            sweep_triangle<true>(a, c, t, order_id(a, t), lane, s_key, n_cov, n_nan, nullptr, s_nanL);
         }
         __syncthreads();
     }
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             um &= um - 1;
             const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)en.x, src);
             uint32_t ncv = 0;
-            sweep_triangle(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(gtab_of(a), tu) : order_id(gtab_of(a), tu), lane, s_key, ncv, n_nan, &s_nanflag);
+            sweep_triangle(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(a, tu) : order_id(a, tu), lane, s_key, ncv, n_nan, &s_nanflag);
             n_cov += ncv;
         }
         const unsigned long long am = __ballot(alive);
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             s_tri[w][trank] = t;
             s_fa[w][trank] = make_float4(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y));
             s_fb[w][trank] = make_float4(u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y));
-            s_fc[w][trank] = make_float2(u2f(q3.z), u2f(PS == FRR_PS_DEPTH ? emission_id(gtab_of(a), en.x) : order_id(gtab_of(a), en.x)));
+            s_fc[w][trank] = make_float2(u2f(q3.z), u2f(PS == FRR_PS_DEPTH ? emission_id(a, en.x) : order_id(a, en.x)));
         }
         // rows of all survivors laid end to end: heads mark where each triangle's rows start
         const uint32_t rincl = wave_incl_scan_dpp(rows);
@@ -997,12 +999,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
                 const int src = __builtin_ctzll(m);
                 m &= m - 1;
                 const uint32_t tu = (uint32_t)__builtin_amdgcn_readlane((int)dent.x, src);
-                sweep_triangle<true>(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(gtab_of(a), tu) : order_id(gtab_of(a), tu), lane, s_key, dummy_cov, dummy_nan, nullptr, s_nanL);
+                sweep_triangle<true>(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(a, tu) : order_id(a, tu), lane, s_key, dummy_cov, dummy_nan, nullptr, s_nanL);
             }
         } else {
             for (uint32_t e = c.beg + (uint32_t)w; e < c.end; e += NW) {
                 const uint32_t tu = __builtin_amdgcn_readfirstlane(ents[e].x);
-                sweep_triangle<true>(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(gtab_of(a), tu) : order_id(gtab_of(a), tu), lane, s_key, dummy_cov, dummy_nan, nullptr, s_nanL);
+                sweep_triangle<true>(a, c, tu, PS == FRR_PS_DEPTH ? emission_id(a, tu) : order_id(a, tu), lane, s_key, dummy_cov, dummy_nan, nullptr, s_nanL);
             }
         }
         __syncthreads();

@@ -290,15 +290,15 @@ int main(int argc, char **argv)
     unsigned long long *out; unsigned *sink;
     hipMalloc(&out, 512 * 16 * 8); hipMalloc(&sink, 4);
     std::vector<unsigned long long> h(512 * 16);
-    const int wps[] = {1, 2, 4, 6, 8};
+    const int wps[] = {1, 2, 4};   // (one workgroup per CU: more than 4 waves per SIMD would need two, and nothing pins those to one CU)
     bool seen_pat = false;
-    printf("cycles per wave64 instruction per SIMD (%d instructions per wave), at W waves per SIMD on every CU\n%-22s", REP * 64, "instruction");
+    printf("cycles per wave64 instruction (or per listed GROUP of instructions) per SIMD, %d per wave, at W waves per SIMD on every CU\n%-38s", REP * 64, "instruction");
     for (int w : wps) printf("  W=%d   ", w);
     printf("\n");
     for (const E &e : tab) {
         if (only_pat && !(e.k == kp_q_cmpnop1 || seen_pat)) continue;
         seen_pat = true;
-        printf("%-22s", e.name);
+        printf("%-38s", e.name);
         for (int w : wps) {
             const int nb = w > 4 ? 2 : 1, nt = w * 256 / nb;
             hipLaunchKernelGGL(e.k, dim3(256 * nb), dim3(nt), 0, 0, out, sink, 7u);
@@ -313,7 +313,7 @@ int main(int argc, char **argv)
     }
     const char *mn[] = {"ds_max_rtn_u64 own", "ds_max_rtn_u64 rand", "ds_read_b128", "ds_read_b32"};
     for (int mode = 0; mode < 4; ++mode) {
-        printf("%-22s", mn[mode]);
+        printf("%-38s", mn[mode]);
         for (int w : wps) {
             const int nb = w > 4 ? 2 : 1, nt = w * 256 / nb;
             hipLaunchKernelGGL(k_lds, dim3(256 * nb), dim3(nt), 0, 0, out, sink, 7u, mode);
