@@ -21,8 +21,11 @@ namespace frr {
 FRR_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 FRR_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
+// Rust's saturating casts and f32::max, two forms each: `*_ref` spells the semantics out (host code, and what the device forms
+// are checked against for all 2^32 operands: frr_debug_rcp_check); the device forms are the single gfx950 instruction that
+// has exactly those semantics -- a compare-and-select chain costs 8+ cycles per link there (tools/valu_rates.hip).
 // Rust `f32 as i32`: truncate, saturate, NaN -> 0  (used at renderer.rs:233-234)
-FRR_HD int32_t f32_as_i32(float f)
+FRR_HD int32_t f32_as_i32_ref(float f)
 {
     if (f != f) return 0;
     if (f >= 2147483648.0f) return INT32_MAX;
@@ -30,14 +33,14 @@ FRR_HD int32_t f32_as_i32(float f)
     return (int32_t)f;
 }
 // Rust `f32 as u32`  (renderer.rs:522-523)
-FRR_HD uint32_t f32_as_u32(float f)
+FRR_HD uint32_t f32_as_u32_ref(float f)
 {
     if (!(f > 0.0f)) return 0u;
     if (f >= 4294967296.0f) return 0xFFFFFFFFu;
     return (uint32_t)f;
 }
 // Rust `f32 as u8` after f32::clamp(0,255) (renderer.rs:9-12): NaN -> 0
-FRR_HD uint32_t quantize_u8(float v)
+FRR_HD uint32_t quantize_u8_ref(float v)
 {
     float x = v * 255.0f;
     if (x < 0.0f) x = 0.0f;
@@ -46,11 +49,49 @@ FRR_HD uint32_t quantize_u8(float v)
     return (uint32_t)x; // x in (0,255]
 }
 // f32::max: NaN operand yields the other
-FRR_HD float f32_max(float a, float b)
+FRR_HD float f32_max_ref(float a, float b)
 {
     if (a != a) return b;
     if (b != b) return a;
     return a > b ? a : b;
+}
+FRR_HD int32_t f32_as_i32(float f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));   // truncates, saturates, NaN -> 0
+    return r;
+#else
+    return f32_as_i32_ref(f);
+#endif
+}
+FRR_HD uint32_t f32_as_u32(float f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));   // truncates, saturates (negative -> 0), NaN -> 0
+    return r;
+#else
+    return f32_as_u32_ref(f);
+#endif
+}
+FRR_HD uint32_t quantize_u8(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t u = f32_as_u32(v * 255.0f);        // negative and NaN -> 0 by the conversion itself
+    return u < 255u ? u : 255u;
+#else
+    return quantize_u8_ref(v);
+#endif
+}
+FRR_HD float f32_max(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the shaders' max(x, 0.0): v_max_f32 is IEEE maxNum (a NaN operand yields the other) and gives +0 for max(-0, +0), as
+    // the comparison form does when b is +0
+    if (__builtin_constant_p(b) && f2u(b) == 0u) return __builtin_fmaxf(a, 0.0f);
+#endif
+    return f32_max_ref(a, b);
 }
 // f32::total_cmp as a signed sortable key (renderer.rs:217)
 FRR_HD int32_t total_order_key(float f)

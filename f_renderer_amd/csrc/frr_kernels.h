@@ -951,8 +951,8 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_seg(RasterArgs a, uint32_t ntile
 namespace frr {
 
 // ---- debug --------------------------------------------------------------------------------
-// recip_exact against the IEEE division, and rsqrt_exact against 1.0f / sqrtf, over a range of bit patterns: number of
-// differing results, first offender
+// recip_exact against the IEEE division, rsqrt_exact against 1.0f / sqrtf, and the single-instruction casts / max of
+// frr_exact.h against their spelled-out forms, over a range of bit patterns: number of differing results, first offender
 __global__ __launch_bounds__(256) void k_debug_rcp(uint32_t lo, uint32_t hi, unsigned long long *bad, uint32_t *first)
 {
     unsigned long long n = 0;
@@ -962,6 +962,9 @@ __global__ __launch_bounds__(256) void k_debug_rcp(uint32_t lo, uint32_t hi, uns
         if (f2u(q) != f2u(r) && !(q != q && r != r)) { ++n; atomicMin(first, (uint32_t)b); }
         const float q2 = 1.0f / sqrtf(s), r2 = rsqrt_exact(s);
         if (f2u(q2) != f2u(r2) && !(q2 != q2 && r2 != r2)) { ++n; atomicMin(first, (uint32_t)b); }
+        const float m = f32_max(s, 0.0f), mr = f32_max_ref(s, 0.0f);
+        if (f32_as_i32(s) != f32_as_i32_ref(s) || f32_as_u32(s) != f32_as_u32_ref(s) || quantize_u8(s) != quantize_u8_ref(s) ||
+            f2u(m) != f2u(mr)) { ++n; atomicMin(first, (uint32_t)b); }
     }
     if (n) atomicAdd(bad, n);
 }
