@@ -5,7 +5,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = os.path.join(R, "gpurun_out", "final3")
 P = os.path.join(R, "profiles")
 TAG = "r03"
-one = lambda pat: sorted(glob.glob(os.path.join(F, pat)))[-1]
+one = lambda pat: max(glob.glob(os.path.join(F, pat)), key=os.path.getmtime)   # (gpurun merges into the local directory: older refreshes may still lie there)
 shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"{TAG}_bench.json"))
 shutil.copy(os.path.join(F, "configs.json"), os.path.join(P, f"{TAG}_configs.json"))
 shutil.copy(os.path.join(F, "bench_in_flight.json"), os.path.join(P, f"{TAG}_bench_in_flight.json"))
