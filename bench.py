@@ -413,7 +413,7 @@ class Run:
             "config": {"workload": self.name, "scene": WORKLOADS[self.name][1], "width": W, "height": H, "triangles": ntris,
                        "setup_triangles": stats["tris_setup"] if world == 1 else None, "covered_fragments": frag_covered,
                        "shader": f"VS_{self.cfg['vs']}/PS_{self.cfg['ps']}", "varyings": self.K, "tile": "32x32",
-                       "frames_in_flight": 2 if self.gathers is None else 1,
+                       "frames_in_flight": 2,   # (N > 1: on the caller-bound target sets, option bound_targets_in_flight)
                        "partition": f"tile rows in {world} contiguous block(s)" + (f", RCCL gather of {gathered} to rank 0" if self.gathers is not None else "")},
         }
         if self._golden_match is not None:
