@@ -601,6 +601,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
 #else
 #define FRR_T(i) do { } while (0)
 #endif
+    // the pre-pass is a chain of dependent loads and barriers: its waves issue ahead of the waves that sit in the row /
+    // fragment loops of other tiles on the same SIMD (the sooner its loads are out, the more of their latency those cover)
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t first_bad = seq_first_bad(a.cnt);   // (tested below, where the first loads are waited for anyway)
     TileCtx c = tile_ctx(a);
     const bool segmented = a.nseg != 0;
@@ -730,6 +733,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
+    __builtin_amdgcn_s_setprio(0);
     const uint32_t le_lo = lane < 32 ? (2u << lane) - 1u : 0xFFFFFFFFu;
     const uint32_t le_hi = lane < 32 ? 0u : (2u << (lane - 32)) - 1u;
     uint32_t n_cov = 0, n_nan = 0;
