@@ -1501,7 +1501,7 @@ int frr_readback_setup(frr_ctx *c, frr_setup_vertex *out, uint64_t cap_tris, uin
                 frr_setup_vertex &o = out[i * 3 + v];
                 memset(&o, 0, sizeof o);
                 o.spf[0] = r.s[2 * s]; o.spf[1] = r.s[2 * s + 1];
-                o.spi[0] = r.p[2 * s]; o.spi[1] = r.p[2 * s + 1];
+                o.spi[0] = f32_as_i32(r.s[2 * s] + 0.5f); o.spi[1] = f32_as_i32(r.s[2 * s + 1] + 0.5f);   // renderer.rs:233-234 (the record keeps spf only)
                 o.rhw = r.rhw[s];
                 for (int k = 0; k < K; ++k) o.ctx[k] = vary[(size_t)slot * 3 * K + (size_t)s * K + k];
             }

@@ -16,12 +16,18 @@ constexpr int GEOM_BLOCK = 256;   // input triangles per geometry workgroup
 // two arrays so the coverage/z loop touches exactly one 64-byte line per triangle:
 //   RasterRec[n]           64 B : post-orientation-swap (renderer.rs:309-312) vertex order
 //   varyings[n][3][K] f32       : same vertex order, read only by the resolve/shade step
+// spi (renderer.rs:233-234) is not stored: it is `(spf + 0.5) as i32` of the stored spf, recomputed by whoever needs it
+// (the brute-force sweep, frr_readback_setup).  Its 24 bytes hold the tile-independent half of the span set-up instead
+// (edge_words below), computed once per triangle by the geometry kernel instead of once per (triangle, tile) pair.
 struct alignas(64) RasterRec {
-    int32_t p[6];    // spi: p0.x p0.y p1.x p1.y p2.x p2.y
-    float s[6];      // spf: same order
+    uint32_t e[6];   // edges 01, 12, 20: {kd, c} -- see edge_words (meaningful for coordinates within +-SPAN_SAFE only)
+    float s[6];      // spf: p0.x p0.y p1.x p1.y p2.x p2.y
     float rhw[3];
-    uint32_t flags;  // bit0: v1/v2 were swapped; bits1..3: edge 01,12,20 is NOT top-left (bias 1)
+    uint32_t flags;  // bit0: v1/v2 were swapped; bits1..3: edge 01,12,20 is NOT top-left (bias 1); bits4..6: A > 0 on that
+                     // edge; bits16..28: the triangle's emission offset within its 256-input geometry block (< 19 * 256)
 };
+constexpr int REC_POS_SHIFT = 4, REC_EOFF_SHIFT = 16;
+constexpr uint32_t REC_EOFF_MASK = 0x1FFFu;
 static_assert(sizeof(RasterRec) == 64, "one cache line per triangle");
 
 #ifdef FRR_DEBUG_COUNTERS
@@ -471,6 +477,30 @@ __device__ __forceinline__ bool tri_rows_owned(const GeomArgs &g, int iy0, int i
 __device__ __forceinline__ bool is_top_left(int ax, int ay, int bx, int by)
 {
     return ((ay == by) && (ax < bx)) || (ay > by);
+}
+
+// The tile-independent half of the span set-up of one edge a -> b (renderer.rs:314-320, 329-341):  A = -(b.y - a.y),
+// B = b.x - a.x,  E(cx, cy) = A (cx - a.x) + B (cy - a.y), accepted where E >= bias (bias 0 for top-left edges, else 1).
+// Row `row` of a bbox-in-tile with origin (bx0, by0) is covered where A dx >= bias - E(bx0, by0 + row); the tile kernel
+// evaluates that as  M = m + k row,  q = floor(M / D)  with  m = c - D bx0 + k by0  (frr_raster.h: SpanTri):
+//   A > 0:  dx >= floor(M / D)     k = -B   D = A    c = bias + A a.x + B a.y + A - 1
+//   A < 0:  dx <= floor(M / D)     k = B    D = -A   c = -bias - A a.x - B a.y
+//   A = 0:  all dx iff M > 0       k = 2B   D = 0    c = 1 - 2 bias - 2 B a.y     (M is odd: never 0)
+// kd = k (low 16 bits, signed) | D << 16.  Exact for coordinates within +-8191 (every product below 2^28); outside that
+// range the words mean nothing and nobody reads them (such triangles take the brute-force sweep).  Wrapping arithmetic.
+struct EdgeWords { uint32_t kd, c, pos; };
+__device__ __forceinline__ EdgeWords edge_words(int ax, int ay, int bx, int by, uint32_t bias)
+{
+    const uint32_t A = 0u - (uint32_t)(by - ay), B = (uint32_t)(bx - ax);
+    const int Ai = (int)A;
+    const uint32_t D = Ai > 0 ? A : 0u - A;
+    const uint32_t axby = A * (uint32_t)ax + B * (uint32_t)ay;
+    EdgeWords w;
+    const uint32_t k = Ai > 0 ? 0u - B : (Ai < 0 ? B : 2u * B);
+    w.c = Ai > 0 ? bias + axby + D - 1u : (Ai < 0 ? 0u - bias - axby : 1u - 2u * bias - 2u * (B * (uint32_t)ay));
+    w.kd = (k & 0xFFFFu) | (D << 16);
+    w.pos = Ai > 0 ? 1u : 0u;
+    return w;
 }
 
 // Pixel bbox of a setup triangle for the binning passes: 4 x i16, saturated (the raster window is

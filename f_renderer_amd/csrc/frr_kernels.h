@@ -322,9 +322,10 @@ constexpr int CLIP_MAXV = 21;
 constexpr int CLIP_QUEUE_AT = 16;   // clipped inputs in one block from which on the block reports itself (the host then switches the clip queue on)
 constexpr int CLIP_INBLOCK = GEOM_BLOCK / 64;   // clipped inputs a geometry block expands itself when the clip queue is in use
 
-// Returns the lane's binning record (all zero for lanes that emit no fan triangle).
+// Returns the lane's binning record (all zero for lanes that emit no fan triangle).  eoff: the input's emission offset
+// within its geometry block (tinfo[t] >> FAN_BITS).
 template <int VS>
-__device__ __forceinline__ uint4 clip_triangle_wave(const GeomArgs &g, const DevUniforms &u, uint32_t t, uint32_t fbase, int lane,
+__device__ __forceinline__ uint4 clip_triangle_wave(const GeomArgs &g, const DevUniforms &u, uint32_t t, uint32_t fbase, uint32_t eoff, int lane,
                                                    float (*s_xy)[2], int32_t *s_key, float (*s_v)[7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)])
 {
     constexpr int NF = VSInfo<VS>::NF, K = VSInfo<VS>::K, KS = K > 0 ? K : 1;
@@ -401,9 +402,14 @@ __device__ __forceinline__ uint4 clip_triangle_wave(const GeomArgs &g, const Dev
         const uint32_t idx = g.ntris + fslot;
         g.fan_okey[fslot] = (t << FAN_BITS) + 1u + (uint32_t)q;
         { const uint2 pb = pack_pbox(p0x, p0y, p1x, p1y, p2x, p2y); mine = make_uint4(pb.x, pb.y, cull_zub(v0[0], v1[0], v2[0]), idx); g.pbox[idx] = mine; }
+        const EdgeWords e01 = edge_words(p0x, p0y, p1x, p1y, (flags >> 1) & 1u);
+        const EdgeWords e12 = edge_words(p1x, p1y, p2x, p2y, (flags >> 2) & 1u);
+        const EdgeWords e20 = edge_words(p2x, p2y, p0x, p0y, (flags >> 3) & 1u);
+        flags |= (e01.pos | (e12.pos << 1) | (e20.pos << 2)) << REC_POS_SHIFT;
+        flags |= (eoff + (uint32_t)q) << REC_EOFF_SHIFT;     // emission offset within the input's geometry block
         uint4 *dst = reinterpret_cast<uint4 *>(g.recs + idx);
-        dst[0] = make_uint4((uint32_t)p0x, (uint32_t)p0y, (uint32_t)p1x, (uint32_t)p1y);
-        dst[1] = make_uint4((uint32_t)p2x, (uint32_t)p2y, f2u(v0[3]), f2u(v0[4]));
+        dst[0] = make_uint4(e01.kd, e01.c, e12.kd, e12.c);
+        dst[1] = make_uint4(e20.kd, e20.c, f2u(v0[3]), f2u(v0[4]));
         dst[2] = make_uint4(f2u(v1[3]), f2u(v1[4]), f2u(v2[3]), f2u(v2[4]));
         dst[3] = make_uint4(f2u(v0[0]), f2u(v1[0]), f2u(v2[0]), flags);
         if constexpr (K > 0) {
@@ -421,7 +427,7 @@ __device__ __forceinline__ uint4 clip_triangle_wave(const GeomArgs &g, const Dev
 // per-triangle prologue of rasterization (:300-320: orientation swap, top-left flags).  Returns the 64-byte record
 // (q0..q3), the binning record, and where input vertices 0 and 1 ended up (d0, d1: for the varyings).
 struct SetupOut { uint4 q0, q1, q2, q3, pbox; int d0, d1; };
-__device__ __forceinline__ SetupOut setup_unclipped(const float pos[3][4], const ScreenVtx &s0, const ScreenVtx &s1, const ScreenVtx &s2)
+__device__ __forceinline__ SetupOut setup_unclipped(const float pos[3][4], const ScreenVtx &s0, const ScreenVtx &s1, const ScreenVtx &s2, uint32_t eoff)
 {
     SetupOut o;
     // centroid (:180-187), n == 3
@@ -488,9 +494,15 @@ __device__ __forceinline__ SetupOut setup_unclipped(const float pos[3][4], const
     flags |= is_top_left(px[0], py[0], px[1], py[1]) ? 0u : 2u;           // :318-320
     flags |= is_top_left(px[1], py[1], px[2], py[2]) ? 0u : 4u;
     flags |= is_top_left(px[2], py[2], px[0], py[0]) ? 0u : 8u;
+    // the tile-independent half of the span set-up (frr_device.h: edge_words), in place of spi
+    const EdgeWords e01 = edge_words(px[0], py[0], px[1], py[1], (flags >> 1) & 1u);
+    const EdgeWords e12 = edge_words(px[1], py[1], px[2], py[2], (flags >> 2) & 1u);
+    const EdgeWords e20 = edge_words(px[2], py[2], px[0], py[0], (flags >> 3) & 1u);
+    flags |= (e01.pos | (e12.pos << 1) | (e20.pos << 2)) << REC_POS_SHIFT;
+    flags |= eoff << REC_EOFF_SHIFT;
     { const uint2 pb = pack_pbox(px[0], py[0], px[1], py[1], px[2], py[2]); o.pbox = make_uint4(pb.x, pb.y, cull_zub(rw[0], rw[1], rw[2]), 0u); }
-    o.q0 = make_uint4((uint32_t)px[0], (uint32_t)py[0], (uint32_t)px[1], (uint32_t)py[1]);
-    o.q1 = make_uint4((uint32_t)px[2], (uint32_t)py[2], f2u(sx[0]), f2u(sy[0]));
+    o.q0 = make_uint4(e01.kd, e01.c, e12.kd, e12.c);
+    o.q1 = make_uint4(e20.kd, e20.c, f2u(sx[0]), f2u(sy[0]));
     o.q2 = make_uint4(f2u(sx[1]), f2u(sy[1]), f2u(sx[2]), f2u(sy[2]));
     o.q3 = make_uint4(f2u(rw[0]), f2u(rw[1]), f2u(rw[2]), flags);
     o.d0 = d0; o.d1 = d1;
@@ -529,6 +541,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     __shared__ int32_t s_ckey[GEOM_BLOCK / 64][CLIP_MAXV];
     __shared__ float s_cv[GEOM_BLOCK / 64][CLIP_MAXV][7 + (VSInfo<VS>::K > 0 ? VSInfo<VS>::K : 1)];
     __shared__ uint32_t s_cl[GEOM_BLOCK];                 // the block's clipped inputs: thread | fan offset within the block << 8
+    __shared__ uint16_t s_ce[GEOM_BLOCK];                 // per thread: its input's emission offset within the block (clipped inputs)
     __shared__ uint32_t s_slot[GEOM_BLOCK / 64][64];      // per wave: the slot of the k-th lane that stores a record (when they are not a run)
     __shared__ uint32_t s_ncl, s_fbase;
     __shared__ uint32_t s_wown[GEOM_BLOCK / 64];          // per wave: triangles it sets up (the block's dense binning entries)
@@ -580,7 +593,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
         if (ftotal) fbase_pending = atomicAdd(&gt->fan_cursor[bid % FAN_REGIONS].v, ftotal);   // (within the block's region)
     }
     if (t < g.ntris) g.tinfo[t] = n | (eoff << FAN_BITS);
-    if (fan_here) s_cl[atomicAdd(&s_ncl, 1u)] = threadIdx.x | (foff << 8);
+    if (fan_here) { s_cl[atomicAdd(&s_ncl, 1u)] = threadIdx.x | (foff << 8); s_ce[threadIdx.x] = (uint16_t)eoff; }
     // Multi-GPU: a rank that owns none of the tile rows an (unclipped) triangle's bbox touches never reads its record
     // (geometry is replicated, so this is what keeps the replicated part small)
     ScreenVtx s0 = {}, s1 = {}, s2 = {};
@@ -600,7 +613,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
     if (threadIdx.x == 0) g.bcount[bid] = own_total;
     if (threadIdx.x >= own_total && t < g.ntris) g.pbox[t] = make_uint4(0u, 0u, 0u, 0u);
     if (emit) {
-    const SetupOut so = setup_unclipped(pos, s0, s1, s2);
+    const SetupOut so = setup_unclipped(pos, s0, s1, s2, eoff);
     {
         const uint32_t dense = own_base + __builtin_amdgcn_mbcnt_hi((uint32_t)(own_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)own_m, 0u));
         g.pbox[bid * GEOM_BLOCK + dense] = make_uint4(so.pbox.x, so.pbox.y, so.pbox.z, t);
@@ -694,7 +707,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_single(GeomArgs g, DevUnifo
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         for (uint32_t e = (uint32_t)w; e < nin; e += GEOM_BLOCK / 64) {
             const uint32_t en = s_cl[e];
-            (void)clip_triangle_wave<VS>(g, u, bid * GEOM_BLOCK + (en & 255u), fbase + (en >> 8), lane, s_cxy[w], s_ckey[w], s_cv[w]);
+            (void)clip_triangle_wave<VS>(g, u, bid * GEOM_BLOCK + (en & 255u), fbase + (en >> 8), s_ce[en & 255u], lane, s_cxy[w], s_ckey[w], s_cv[w]);
         }
     }
 }
@@ -712,7 +725,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void k_geom_clip(GeomArgs g, DevUniform
     const uint32_t stride = gridDim.x * (GEOM_BLOCK / 64);
     for (uint32_t e = blockIdx.x * (GEOM_BLOCK / 64) + (uint32_t)w; e < n; e += stride) {
         const uint2 q = g.clipq[e];
-        (void)clip_triangle_wave<VS>(g, u, q.x, q.y, lane, s_cxy[w], s_ckey[w], s_cv[w]);
+        (void)clip_triangle_wave<VS>(g, u, q.x, q.y, g.tinfo[q.x] >> FAN_BITS, lane, s_cxy[w], s_ckey[w], s_cv[w]);
     }
 }
 

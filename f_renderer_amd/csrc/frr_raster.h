@@ -61,6 +61,15 @@ __device__ __forceinline__ uint32_t emission_id(const RasterArgs &a, uint32_t sl
     if (slot >= nt) { const uint32_t ok = a.fan_okey[slot - nt]; t = ok >> FAN_BITS; q = (ok & ((1u << FAN_BITS) - 1u)) - 1u; }
     return 1u + a.block_prefix[t / GEOM_BLOCK] + (a.tinfo[t] >> FAN_BITS) + q;
 }
+// the same from the flags word of the triangle's record (its emission offset within its geometry block travels there):
+// one table lookup instead of two dependent ones
+__device__ __forceinline__ uint32_t emission_id_rec(const RasterArgs &a, uint32_t slot, uint32_t flags)
+{
+    const uint32_t nt = a.ntris_draw;
+    uint32_t t = slot;
+    if (slot >= nt) t = a.fan_okey[slot - nt] >> FAN_BITS;
+    return 1u + a.block_prefix[t / GEOM_BLOCK] + ((flags >> REC_EOFF_SHIFT) & REC_EOFF_MASK);
+}
 // the slot of the triangle with emission index e (within the draw): two binary searches; only the depth-only resolve's
 // rare re-evaluation (-0.0 / NaN depths) needs it
 __device__ __forceinline__ uint32_t slot_of_emission(const RasterArgs &cnt, uint32_t e)
@@ -257,7 +266,10 @@ __device__ __forceinline__ void sweep_triangle(const RasterArgs &a, const TileCt
                                                const uint32_t *nanL = nullptr)
 {
     const RasterRec *__restrict__ r = a.recs + t;
-    const int p0x = r->p[0], p0y = r->p[1], p1x = r->p[2], p1y = r->p[3], p2x = r->p[4], p2y = r->p[5];
+    const float s0x = r->s[0], s0y = r->s[1], s1x = r->s[2], s1y = r->s[3], s2x = r->s[4], s2y = r->s[5];
+    // spi = (spf + 0.5) as i32 (renderer.rs:233-234; the record keeps spf only)
+    const int p0x = f32_as_i32(s0x + 0.5f), p0y = f32_as_i32(s0y + 0.5f), p1x = f32_as_i32(s1x + 0.5f), p1y = f32_as_i32(s1y + 0.5f);
+    const int p2x = f32_as_i32(s2x + 0.5f), p2y = f32_as_i32(s2y + 0.5f);
     // clamped bbox (renderer.rs:285-298; clamp is monotone so it commutes with min/max)
     int bx0 = clampi(min(p0x, min(p1x, p2x)), a.x0, a.x1), bx1 = clampi(max(p0x, max(p1x, p2x)), a.x0, a.x1);
     int by0 = clampi(min(p0y, min(p1y, p2y)), a.y0, a.y1), by1 = clampi(max(p0y, max(p1y, p2y)), a.y0, a.y1);
@@ -276,7 +288,6 @@ __device__ __forceinline__ void sweep_triangle(const RasterArgs &a, const TileCt
     const uint32_t fl = r->flags;
     // reject E < bias  <=>  accept E > bias-1   (bias 0 for top-left edges, else 1; :333-341)
     const int thr01 = (fl & 2u) ? 0 : -1, thr12 = (fl & 4u) ? 0 : -1, thr20 = (fl & 8u) ? 0 : -1;
-    const float s0x = r->s[0], s0y = r->s[1], s1x = r->s[2], s1y = r->s[3], s2x = r->s[4], s2y = r->s[5];
     const float r0 = r->rhw[0], r1 = r->rhw[1], r2 = r->rhw[2];
     // p -> (dx, dy): dy = floor((p + 0.5) / bw) via a 1-ulp reciprocal, exact for p < 1024, bw <= 32
     const float inv_bw = __builtin_amdgcn_rcpf((float)bw);
@@ -422,8 +433,9 @@ __device__ __forceinline__ void seg_advance(uint32_t h_lo, uint32_t h_hi, int &b
 // branches: M(row) = m + k*row, q = floor(M / D), and
 //   A > 0:  dx >= ceil(N/A) = floor((N + A - 1)/A)      m = n + A - 1,  k = -B,  D = A,   q bounds lo
 //   A < 0:  dx <= floor(-N/|A|)                         m = -n,         k = B,   D = |A|, q + 1 bounds hi
-//   A = 0:  all dx if N <= 0, none otherwise            m = 1 - 2n,     k = 2B,  D = 1,   "reciprocal" 64: M is odd, so
-//           the quotient is >= 39 (hi unchanged: a row has at most 32 pixels) or <= -1 (hi <= 0)
+//   A = 0:  all dx if N <= 0, none otherwise            m = 1 - 2n,     k = 2B,  D = 0,   "reciprocal" 64: M is odd, so
+//           the quotient is >= 41 (hi unchanged: a row has at most 32 pixels) or <= -3 (hi <= 0)
+// k, D and the tile-independent part of m come from the geometry kernel (frr_device.h: edge_words, RasterRec::e).
 struct alignas(16) SpanTri {
     int32_t m01, m12, m20;     // M at row 0
     uint32_t zub;              // zkey of an upper bound of rhw over the triangle
@@ -431,20 +443,6 @@ struct alignas(16) SpanTri {
     uint32_t misc;             // bx0l:5 | by0l:5 <<5 | bw:6 <<10 | (A > 0) per edge <<16
     float r01, r12, r20, pad;  // v_rcp_f32 of D per edge
 };
-struct SpanEdge { int32_t m; uint32_t kd; float r; uint32_t pos; };
-__device__ __forceinline__ SpanEdge span_edge_setup(int A, int B, int n)
-{
-    SpanEdge e;
-    const int D = A > 0 ? A : -A;
-    if (A > 0) { e.m = n + D - 1; e.kd = ((uint32_t)(-B) & 0xFFFFu) | ((uint32_t)D << 16); e.pos = 1u; }
-    else if (A < 0) { e.m = -n; e.kd = ((uint32_t)B & 0xFFFFu) | ((uint32_t)D << 16); e.pos = 0u; }
-    else {
-        const int nc = min(max(n, -(1 << 24)), 1 << 24);   // |B*row| < 2^19: the sign of N survives the clamp
-        e.m = 1 - 2 * nc; e.kd = ((uint32_t)(2 * B) & 0xFFFFu) | (1u << 16); e.pos = 0u;
-    }
-    e.r = A ? __builtin_amdgcn_rcpf((float)D) : 64.0f;      // the 1-ulp reciprocal, once per triangle
-    return e;
-}
 // narrows [lo, hi) by one edge; pmask = -1 for A > 0 else 0.  Only quotients in [0, 32] matter: the float quotient is
 // clamped to [-2, 40] and ONE remainder step makes every in-range quotient exact (out-of-range ones stay out of range).
 __device__ __forceinline__ void span_edge_bound(int m, uint32_t kd, float rD, int pmask, int row, int &lo, int &hi)
@@ -667,9 +665,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         return a.bins[s_segsrc[g] + (k - s_segpre[g])];
     };
     tile_load_keys(a, c, s_key, ~0ull);
-    if (threadIdx.x == 0) { s_next = 0; s_dirty = 1u; s_nanflag = 0u; }
+    // A draw that carries the frame's clear starts from ONE depth: the minima are that constant (pixels of a partial tile
+    // beyond the window would only raise them), and nothing has to be rebuilt before the first fragments land.  Else:
+    // "nothing can be culled" until the first rebuild.
+    const uint32_t hz0 = a.fused_clear ? zkey_depth(a.clear_depth) : 0u;
+    if (threadIdx.x == 0) { s_next = 0; s_dirty = a.fused_clear ? 0u : 1u; s_nanflag = 0u; }
     for (int i = threadIdx.x; i < BKT_N; i += NW * 64) s_bkt[i] = 0;
-    for (int i = threadIdx.x; i < HZ_SIZE; i += NW * 64) s_hz[i] = 0u; // "nothing can be culled" until the first rebuild lands
+    for (int i = threadIdx.x; i < HZ_SIZE; i += NW * 64) s_hz[i] = i >= HZ_C4 ? hz0 >> 1 : hz0;
     __syncthreads();
 
     // ---- pre-pass: this tile's 16-byte cull records {triangle, zkey of an upper bound of its rhw
@@ -827,31 +829,23 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         if (alive) {
             const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + en.x);
             const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
-            const int p0x = (int)q0.x, p0y = (int)q0.y, p1x = (int)q0.z, p1y = (int)q0.w, p2x = (int)q1.x, p2y = (int)q1.y;
-            // edge functions E = A*(cx - px) + B*(cy - py) (renderer.rs:329-331); nothing wraps for `safe` triangles
-            const int A01 = -(p1y - p0y), B01 = p1x - p0x;
-            const int A12 = -(p2y - p1y), B12 = p2x - p1x;
-            const int A20 = -(p0y - p2y), B20 = p0x - p2x;
-            // at the bbox-in-tile origin; every factor of a `safe` triangle is below 2^15: 24-bit multiplies are exact
-            const int e01 = __mul24(A01, bx0 - p0x) + __mul24(B01, by0 - p0y);
-            const int e12 = __mul24(A12, bx0 - p1x) + __mul24(B12, by0 - p1y);
-            const int e20 = __mul24(A20, bx0 - p2x) + __mul24(B20, by0 - p2y);
-            // accept E > thr, thr = -1 for top-left edges, else 0 (:333-341): a row needs A*dx >= (thr + 1 - E_row)
-            const SpanEdge g01 = span_edge_setup(A01, B01, (int)((q3.w >> 1) & 1u) - e01);
-            const SpanEdge g12 = span_edge_setup(A12, B12, (int)((q3.w >> 2) & 1u) - e12);
-            const SpanEdge g20 = span_edge_setup(A20, B20, (int)((q3.w >> 3) & 1u) - e20);
+            // the record carries each edge as {kd, c} (frr_device.h: edge_words); what depends on the tile is M at the
+            // origin of the bbox-in-tile, m = c - D bx0 + k by0 -- every factor of a `safe` triangle is below 2^15, the
+            // 24-bit multiplies are exact -- and the 1-ulp reciprocal of D (D = 0, an A = 0 edge: 64, see SpanTri)
+            auto m_of = [&](uint32_t kd, uint32_t cc) { return (int)cc + __mul24((int)(kd << 16) >> 16, by0) - __mul24((int)(kd >> 16), bx0); };
+            auto r_of = [&](uint32_t kd) { return fminf(__builtin_amdgcn_rcpf((float)(kd >> 16)), 64.0f); };
             SpanTri t;
-            t.m01 = g01.m; t.m12 = g12.m; t.m20 = g20.m;
+            t.m01 = m_of(q0.x, q0.y); t.m12 = m_of(q0.z, q0.w); t.m20 = m_of(q1.x, q1.y);
             t.zub = en.y;                        // zkey of an upper bound of rhw over the triangle (cull_zub)
-            t.kd01 = g01.kd; t.kd12 = g12.kd; t.kd20 = g20.kd;
+            t.kd01 = q0.x; t.kd12 = q0.z; t.kd20 = q1.x;
             t.misc = (uint32_t)(bx0 - c.ax0) | ((uint32_t)(by0 - c.ay0) << 5) | ((uint32_t)(bx1 - bx0) << 10) |
-                     (g01.pos << 16) | (g12.pos << 17) | (g20.pos << 18);
-            t.r01 = g01.r; t.r12 = g12.r; t.r20 = g20.r;
+                     (((q3.w >> REC_POS_SHIFT) & 7u) << 16);
+            t.r01 = r_of(q0.x); t.r12 = r_of(q0.z); t.r20 = r_of(q1.x);
             t.pad = 0.0f;
             s_tri[w][trank] = t;
             s_fa[w][trank] = make_float4(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y));
             s_fb[w][trank] = make_float4(u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y));
-            s_fc[w][trank] = make_float2(u2f(q3.z), u2f(PS == FRR_PS_DEPTH ? emission_id(a, en.x) : order_id(a, en.x)));
+            s_fc[w][trank] = make_float2(u2f(q3.z), u2f(PS == FRR_PS_DEPTH ? emission_id_rec(a, en.x, q3.w) : order_id(a, en.x)));
         }
         // rows of all survivors laid end to end: heads mark where each triangle's rows start
         const uint32_t rincl = wave_incl_scan_dpp(rows);
