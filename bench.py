@@ -43,7 +43,11 @@ WORKLOADS = {
 }
 ALIASES = {cfg: name for name, (cfg, _) in WORKLOADS.items()}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROF_PERIOD = 8             # k_raster launches are bracketed by HIP events only every 8th time (an event pair costs the stream ~4 us)
+PROF_PERIOD = 4             # timed region: k_raster launches are bracketed by HIP events only every 4th time (an event pair costs the stream ~4 us)
+ISO_LAUNCHES = 16           # launches of the dominant kernel timed one frame at a time (the primary roofline figure)
+SIMDS, CLOCK_GHZ = 1024, 2.4   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2400 MHz max clock (the VALU-issue bound is priced at the max clock)
+DEFAULT_FIF = int(os.environ.get("FRR_FRAMES_IN_FLIGHT", "2"))   # what f_renderer_amd.Renderer sets from the environment (dev runs)
+DEFAULT_OVERLAP = int(os.environ.get("FRR_OVERLAP", "2"))
 
 
 def parse_args():
@@ -81,19 +85,21 @@ def source_sha():
 
 
 def load_pmc_traffic(workload):
-    """(HBM bytes per k_raster launch, stale?) from a committed rocprofv3 --pmc run (profiles/pmc_traffic.json)."""
+    """(HBM bytes per k_raster launch, VALU-issue entry or None, stale?) from a committed rocprofv3 --pmc run
+    (profiles/pmc_traffic.json, written by tools/make_pmc_traffic.py; reported only while the kernel sources are the ones
+    the counters were measured on)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             d = json.load(fh)
         e = d.get(workload, {})
         k = e.get("k_raster")
         if not k:
-            return None, False
+            return None, None, False
         if e.get("_source_sha") != source_sha():
-            return None, True
-        return float(k["hbm_bytes_per_launch"]), False
+            return None, None, True
+        return float(k["hbm_bytes_per_launch"]), k.get("valu_issue"), False
     except Exception:
-        return None, False
+        return None, None, False
 
 
 def golden_counts(cfg_name):
@@ -337,17 +343,31 @@ class Run:
             r.sync()
             stats = r.stats()
 
-            # the tile kernel on its own: a few frames issued one at a time (the library keeps two frames in flight on its own
-            # targets, so in the timed region below the kernel shares the chip with the next frame's geometry and binning)
-            self._raster_iso = (0.0, 0)
+            # One frame at a time (what a caller that reads every frame back gets: the reference's loop is serial,
+            # phong.rs:314-387): the frame period, and the dominant kernel's launches with nothing beside them -- the
+            # primary roofline figure.  (In the timed region below the library keeps two frames in flight: there the
+            # kernel shares the chip with the next frame's geometry + binning, and consecutive tile kernels may overlap.)
+            self._raster_iso, self._serial_ms = (0.0, 0), None
             if self.gathers is None:
+                r.set_option("frames_in_flight", 1)
+                r.set_option("overlap", 0)
+                for _ in range(3):
+                    self.step()
+                r.sync()
+                n1 = max(8, min(steps, 20))
+                self._serial_ms = self.timed_loop(n1) / n1 * 1e3
                 r.profile_reset()
                 r.profile_enable(True, kernels=["k_raster"], period=1)
-                for _ in range(6):
+                for _ in range(ISO_LAUNCHES):
                     self.step()
                     r.sync()
                 self._raster_iso = r.profile_get("k_raster")
                 r.profile_enable(False)
+                r.set_option("frames_in_flight", DEFAULT_FIF)
+                r.set_option("overlap", DEFAULT_OVERLAP)
+                for _ in range(3):
+                    self.step()
+                r.sync()
 
             r.profile_reset()
             r.profile_enable(True, kernels=["k_raster"], period=PROF_PERIOD)
@@ -413,7 +433,7 @@ class Run:
             "config": {"workload": self.name, "scene": WORKLOADS[self.name][1], "width": W, "height": H, "triangles": ntris,
                        "setup_triangles": stats["tris_setup"] if world == 1 else None, "covered_fragments": frag_covered,
                        "shader": f"VS_{self.cfg['vs']}/PS_{self.cfg['ps']}", "varyings": self.K, "tile": "32x32",
-                       "frames_in_flight": 2,   # (N > 1: on the caller-bound target sets, option bound_targets_in_flight)
+                       "frames_in_flight": DEFAULT_FIF,   # (N > 1: on the caller-bound target sets, option bound_targets_in_flight)
                        "partition": f"tile rows in {world} contiguous block(s)" + (f", RCCL gather of {gathered} to rank 0" if self.gathers is not None else "")},
         }
         if self._golden_match is not None:
@@ -428,35 +448,56 @@ class Run:
         return out
 
     def roofline(self, out, f_pass, n_setup):
-        """Roofline of the dominant kernel (k_raster): algorithmic bytes per launch:
+        """Roofline of the dominant kernel (k_raster).  Algorithmic bytes per launch:
           N_setup * (108 + 12K) record bytes read by the raster pass
-        + 4 B depth read per covered fragment + 8 B (depth+colour/id write) per z-passing fragment."""
+        + 4 B depth read per covered fragment + 8 B (depth + colour/id write) per z-passing fragment;
+        `frac_fragment_pass` is the literal fragment-pass form (4 F_cov + 8 F_pass only).  The primary figures come from
+        launches with nothing beside them (one frame at a time); `in_flight` is the same kernel in the timed region."""
         raster_ms, raster_n = self._raster
-        if not raster_n:
-            return
-        avg_ms = raster_ms / raster_n
-        if self.world == 1 and f_pass is not None:
-            alg = n_setup * (108 + 12 * self.K) + 4 * self._frag_covered + 8 * f_pass
-            ach = alg / (avg_ms * 1e-3) / 1e9
-            traffic, stale = load_pmc_traffic(self.name)
-            out["roofline"] = {"bound": "hbm", "kernel": "k_raster", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg_ms, 5),
-                               "launches": raster_n, "sampled_every": PROF_PERIOD, "frag_zpass": f_pass,
-                               "note": "achieved = ALGORITHMIC bytes (the reference's memory semantics) / launch time, an efficiency "
-                                       "figure; the kernel resolves depth in LDS, its measured HBM bytes are `traffic`.  In the timed "
-                                       "region two frames are in flight: the kernel runs beside the next frame's geometry + binning "
-                                       "(`isolated`: the same kernel with one frame issued at a time)"}
-            iso_ms, iso_n = self._raster_iso
-            if iso_n:
-                out["roofline"]["isolated"] = {"avg_launch_ms": round(iso_ms / iso_n, 5), "launches": iso_n,
-                                               "achieved": round(alg / (iso_ms / iso_n * 1e-3) / 1e9, 1),
-                                               "frac": round(alg / (iso_ms / iso_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        iso_ms, iso_n = self._raster_iso
+        ms_per_step = out["ms_per_step"]
+        if self._serial_ms is not None:
+            out["ms_per_frame_serial"] = round(self._serial_ms, 5)
+        if self.world == 1 and f_pass is not None and (iso_n or raster_n):
+            K, F_cov = self.K, self._frag_covered
+            nf = self.fr.lib().frr_vs_input_floats(self.vs)
+            alg = n_setup * (108 + 12 * K) + 4 * F_cov + 8 * f_pass
+            frag_alg = 4 * F_cov + 8 * f_pass
+            # the whole frame's algorithmic bytes (SURVEY 8d: B_alg) and what the frame period makes of them
+            frame_alg = self.ntris * nf * 12 + 2 * n_setup * (108 + 12 * K) + frag_alg + 8 * self.W * self.H
+            out["frame_alg_bytes"] = frame_alg
+            out["frame_alg_gbs"] = round(frame_alg / (ms_per_step * 1e-3) / 1e9, 1)
+            traffic, valu, stale = load_pmc_traffic(self.name)
+            fig = lambda ms: {"avg_launch_ms": round(ms, 5), "achieved": round(alg / (ms * 1e-3) / 1e9, 1),  # noqa: E731
+                              "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "frac_fragment_pass": round(frag_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            prim_ms, prim_n, mode = (iso_ms / iso_n, iso_n, "one frame at a time") if iso_n else (raster_ms / raster_n, raster_n, "timed region")
+            roof = {"bound": "hbm", "kernel": "k_raster", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,
+                    "algorithmic_bytes_per_launch": alg, "fragment_pass_bytes_per_launch": frag_alg, "frag_zpass": f_pass,
+                    "launches": prim_n, "measured": mode}
+            roof.update(fig(prim_ms))
+            if raster_n and iso_n:
+                avg = raster_ms / raster_n
+                if avg <= ms_per_step:
+                    roof["in_flight"] = dict(fig(avg), launches=raster_n, sampled_every=PROF_PERIOD)
+                else:   # consecutive frames' tile kernels overlapped: the event bracket timed a time-shared kernel
+                    roof["in_flight"] = {"dropped": "avg_launch_ms %.5f > ms_per_step: overlapping launches" % avg, "launches": raster_n}
+            roof["note"] = ("achieved = ALGORITHMIC bytes (the reference's memory semantics) / launch time, an efficiency figure; "
+                            "the kernel resolves depth in LDS, its measured HBM bytes are `traffic`; the kernel is bound by VALU "
+                            "issue, see `valu_issue`")
+            if valu:
+                # VALU-issue bound: instructions the launch issues (PMC) x the measured issue cost per instruction kind
+                # (profiles/*valu_issue_rates.txt, weighted by the static mix of the kernel's hot loops) / SIMD cycles available
+                cyc = valu["insts_valu"] * valu["cycles_per_valu"]
+                roof["valu_issue"] = {"bound": "valu_issue", "insts_valu": valu["insts_valu"], "insts_salu": valu.get("insts_salu"),
+                                      "cycles_per_valu": valu["cycles_per_valu"], "simds": SIMDS, "clock_ghz": CLOCK_GHZ,
+                                      "frac": round(cyc / (SIMDS * prim_ms * 1e-3 * CLOCK_GHZ * 1e9), 4)}
             if stale:
-                out["roofline"]["traffic_stale"] = "profiles/pmc_traffic.json was measured on other kernel sources"
-        else:
+                roof["traffic_stale"] = "profiles/pmc_traffic.json was measured on other kernel sources"
+            out["roofline"] = roof
+        elif raster_n:
             out["roofline"] = {"bound": "hbm", "kernel": "k_raster", "achieved": None, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                               "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_ms": round(raster_ms / raster_n, 5),
                                "launches": raster_n,
                                "note": "per-rank launch covers 1/N of the tiles; algorithmic bytes are quoted at N=1"}
 

@@ -405,28 +405,14 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-// A 64-bit "heads" mask marks where segments start inside a window of 64 consecutive items.
-// For lane L: k = number of heads at positions <= L, off = distance to the nearest head at or
-// before L (or L + carry when the segment started in an earlier window).
-struct SegPos { int k, off; };
-__device__ __forceinline__ SegPos seg_locate(uint32_t h_lo, uint32_t h_hi, uint32_t le_lo, uint32_t le_hi, int lane, int carry)
+// A 64-bit "heads" mask marks where segments start inside a window of 64 consecutive items: the segment of lane L is
+// the (number of heads at positions <= L)-th one.  seg_rank: its index, given `base` = (heads in earlier windows) - 1.
+// (Where a segment STARTS travels with the segment's own data -- SpanTri::misc, the span descriptors -- so nobody has
+// to look for its head, also not across windows.)
+__device__ __forceinline__ int seg_rank(uint32_t h_lo, uint32_t h_hi, uint32_t le_lo, uint32_t le_hi, int base)
 {
-    const uint32_t m_lo = h_lo & le_lo, m_hi = h_hi & le_hi;
-    SegPos s;
-    s.k = __popc(m_lo) + __popc(m_hi);
-    // leading zeros of the 64-bit mask (64 if it is empty), straight-line code
-    const int z = __clzll(((unsigned long long)m_hi << 32) | (unsigned long long)m_lo);
-    s.off = z < 64 ? lane - 63 + z : lane + carry;
-    return s;
+    return __popc(h_hi & le_hi) + (__popc(h_lo & le_lo) + base);
 }
-// scalar bookkeeping for the next window: heads consumed, and how far into the open segment we are
-__device__ __forceinline__ void seg_advance(uint32_t h_lo, uint32_t h_hi, int &base, int &carry)
-{
-    const int last = h_hi ? 63 - __clz((int)h_hi) : (h_lo ? 31 - __clz((int)h_lo) : -1);
-    carry = last >= 0 ? 64 - last : carry + 64;
-    base += __popc(h_lo) + __popc(h_hi);
-}
-
 // Per-triangle data of the span phase (48 bytes).  Row `row` of the triangle's bbox-in-tile is covered by the dx in
 // [lo, hi) that satisfy A*dx >= N(row) on all three edges, N(row) = (thr + 1 - E at the bbox origin) - B*row, thr = -1
 // for top-left edges else 0 (renderer.rs:329-341).  Each edge is stored in the form the row lanes evaluate without
@@ -440,7 +426,7 @@ struct alignas(16) SpanTri {
     int32_t m01, m12, m20;     // M at row 0
     uint32_t zub;              // zkey of an upper bound of rhw over the triangle
     uint32_t kd01, kd12, kd20; // k (low 16, signed) | D (high 16)
-    uint32_t misc;             // bx0l:5 | by0l:5 <<5 | bw:6 <<10 | (A > 0) per edge <<16
+    uint32_t misc;             // bx0l:5 | by0l:5 <<5 | bw:6 <<10 | (A > 0) per edge <<16 | position of the triangle's first row among the step's rows <<19
     float r01, r12, r20, pad;  // v_rcp_f32 of D per edge
 };
 // narrows [lo, hi) by one edge; pmask = -1 for A > 0 else 0.  Only quotients in [0, 32] matter: the float quotient is
@@ -562,6 +548,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
 {
     constexpr int B = NW <= 3 ? LIGHT_B : (OCC >= 8 || NW >= 16) ? 16 : SPAN_BATCH; // staged triangles per wave (LDS budget: 8 workgroups per CU; 64 KiB of static LDS at NW = 16)
     constexpr bool TEXTURED = PS == FRR_PS_PHONG || PS == FRR_PS_BLINN || PS >= FRR_SHADER_USER_BASE;   // (the u8 -> float table of sample_2d)
+    static_assert(B <= 32, "staging slots are five bits of a span descriptor, first rows ten bits of SpanTri::misc");
     using L = SpanLds<NW, B>;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[L::bytes(TEXTURED)];
     unsigned long long *const s_key = reinterpret_cast<unsigned long long *>(s_raw + L::KEY);
@@ -826,6 +813,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         if (am == 0ull) continue;
         const int trank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
         const uint32_t rows = alive ? (uint32_t)(by1 - by0) : 0u;
+        // rows of all survivors laid end to end (at most B * 32 = 1024 of them): heads mark where each triangle's rows start
+        const uint32_t rincl = wave_incl_scan_dpp(rows);
         if (alive) {
             const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + en.x);
             const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
@@ -839,7 +828,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             t.zub = en.y;                        // zkey of an upper bound of rhw over the triangle (cull_zub)
             t.kd01 = q0.x; t.kd12 = q0.z; t.kd20 = q1.x;
             t.misc = (uint32_t)(bx0 - c.ax0) | ((uint32_t)(by0 - c.ay0) << 5) | ((uint32_t)(bx1 - bx0) << 10) |
-                     (((q3.w >> REC_POS_SHIFT) & 7u) << 16);
+                     (((q3.w >> REC_POS_SHIFT) & 7u) << 16) | ((rincl - rows) << 19);
             t.r01 = r_of(q0.x); t.r12 = r_of(q0.z); t.r20 = r_of(q1.x);
             t.pad = 0.0f;
             s_tri[w][trank] = t;
@@ -847,8 +836,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             s_fb[w][trank] = make_float4(u2f(q2.z), u2f(q2.w), u2f(q3.x), u2f(q3.y));
             s_fc[w][trank] = make_float2(u2f(q3.z), u2f(PS == FRR_PS_DEPTH ? emission_id_rec(a, en.x, q3.w) : order_id(a, en.x)));
         }
-        // rows of all survivors laid end to end: heads mark where each triangle's rows start
-        const uint32_t rincl = wave_incl_scan_dpp(rows);
         const int R = (int)__builtin_amdgcn_readlane((int)rincl, 63);
         if (lane < B / 2) s_hrow[w][lane] = 0ull;
         wave_lds_fence();
@@ -860,20 +847,19 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
         const unsigned long long hrow_mine = s_hrow[w][lane & (B / 2 - 1)]; // lane i keeps the heads of row window i
         wave_lds_fence();
 
-        int jbase = 0, jcarry = 0; // heads seen in earlier row windows; rows of the open triangle already done
+        int jbase = 0;             // heads seen in earlier row windows
         FRR_T(3);
         for (int r0 = 0; r0 < R; r0 += 64) {
             // ---- phase 2: lane = (triangle, row).  Exact covered span of that row. ----
             const uint32_t h_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hrow_mine, r0 >> 6);
             const uint32_t h_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hrow_mine >> 32), r0 >> 6);
-            const SegPos sp = seg_locate(h_lo, h_hi, le_lo, le_hi, lane, jcarry);
             const bool ractive = r0 + lane < R;
-            const int j = jbase + sp.k - 1;                                    // staging slot = rank of the triangle
+            const int j = seg_rank(h_lo, h_hi, le_lo, le_hi, jbase - 1);       // staging slot = rank of the triangle
             int len = 0, xl = 0, yl = 0;
             uint32_t zu = 0xFFFFFFFFu;
             if (ractive) {
                 const SpanTri ti = s_tri[w][j];
-                const int row = sp.off;
+                const int row = r0 + lane - (int)(ti.misc >> 19);
                 const int bwj = (int)((ti.misc >> 10) & 63u);
                 int lo = 0, hi = bwj;
                 span_edge_bound(ti.m01, ti.kd01, ti.r01, (int)(ti.misc << 15) >> 31, row, lo, hi);
@@ -887,7 +873,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
 #ifdef FRR_DEBUG_COUNTERS
             d_rwin++; d_rows += __popcll(__ballot(ractive)); d_spans += __popcll(__ballot(len > 0));
 #endif
-            seg_advance(h_lo, h_hi, jbase, jcarry);
+            jbase += __popc(h_lo) + __popc(h_hi);
             if (COUNT) n_cov += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp((uint32_t)len), 63);
             // span-level early-z against the minima of the row's eight 4-pixel cells: the span shrinks to
             // the hull of the cells in which the triangle's depth bound could still win
@@ -929,7 +915,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
             if (len > 0) {
                 const uint32_t st = fincl - (uint32_t)len;
                 atomicOr(reinterpret_cast<uint32_t *>(&s_hfrag[w][0]) + (st >> 5), 1u << (st & 31));
-                s_q[w][srank] = (uint32_t)j | ((uint32_t)yl << 6) | ((uint32_t)xl << 11); // span descriptor
+                // span descriptor: staging slot, row, and x of the span's first pixel MINUS its first fragment's position (+ 2048:
+                // a window holds at most 64 * 32 fragments), so that fragment f of the window is pixel x = field + f - 2048
+                s_q[w][srank] = (uint32_t)j | ((uint32_t)yl << 5) | (((uint32_t)xl + 2048u - st) << 10);
             }
             wave_lds_fence();
             const unsigned long long hfrag_mine = s_hfrag[w][lane & 31]; // lane i keeps the heads of fragment window i
@@ -938,15 +926,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
 #ifdef FRR_DEBUG_COUNTERS
             d_frags += F; d_fwin += (F + 63) / 64;
 #endif
-            int qbase = 0, qcarry = 0;
+            int qbase = 0;
             FRR_T(4);
             for (int f0 = 0; f0 < F; f0 += 64) {
                 const uint32_t g_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hfrag_mine, f0 >> 6);
                 const uint32_t g_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hfrag_mine >> 32), f0 >> 6);
-                const SegPos fp = seg_locate(g_lo, g_hi, le_lo, le_hi, lane, qcarry);
                 if (f0 + lane < F) {
-                    const uint32_t d = s_q[w][qbase + fp.k - 1];
-                    const int sj = (int)(d & 63u), y = (int)((d >> 6) & 31u), x = (int)((d >> 11) & 31u) + fp.off;
+                    const uint32_t d = s_q[w][seg_rank(g_lo, g_hi, le_lo, le_hi, qbase - 1)];
+                    const int sj = (int)(d & 31u), y = (int)((d >> 5) & 31u), x = (int)(d >> 10) + (f0 - 2048) + lane;
                     const float4 fa = s_fa[w][sj], fb = s_fb[w][sj];
                     const float2 fc = s_fc[w][sj];
                     Frag f = frag_eval(fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w, fc.x, c.ax0 + x, c.ay0 + y);
@@ -962,7 +949,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_raster_span(RasterArgs a, DevU
 #endif
                     }
                 }
-                seg_advance(g_lo, g_hi, qbase, qcarry);
+                qbase += __popc(g_lo) + __popc(g_hi);
             }
             if (lane == 0) s_dirty = 1u;
             wave_lds_fence(); // s_q / s_hfrag are rewritten by the next row window
