@@ -278,7 +278,13 @@ class Run:
         g = self.gathers if gather else None
         if self.gathers is not None:
             if self.inflight[s] is not None:            # the gather that last read this target set must be done
-                self.final = self.gathers[s].finish(self.inflight[s]) if sync_gather else self.gathers[s].finish_host(self.inflight[s])
+                if sync_gather:
+                    # stream-side completion only: this stream now waits for the exchange, and the frame about to render into
+                    # the set runs on one of the library's private streams -- its first write of the targets waits for this stream
+                    self.final = self.gathers[s].finish(self.inflight[s])
+                    self.r.frame_wait(self.stream.cuda_stream)
+                else:
+                    self.final = self.gathers[s].finish_host(self.inflight[s])   # (the host has seen it complete)
                 self.inflight[s] = None
             self.r.bind_targets(self.color[s].data_ptr(), self.depth[s].data_ptr(), self.tri_id[s].data_ptr())
         self.r.clear((30, 30, 30, 255), 0.0)

@@ -111,29 +111,33 @@ int main(int argc, char **argv)
         void *color, *depth, *ids;
         CHECK_FRR(ctx, frr_target_ptrs(ctx, &color, &depth, &ids));                    // device pointers, row stride W * 4 bytes
         (void)color;
-        // ONE group per frame, on the ctx's stream (so it is ordered after the frame's tile kernels)
+        // ONE group per frame, on the ctx's stream (so it is ordered after the frame's tile kernels; and the library orders
+        // the frame that next renders into this target set -- two frames on -- behind what this stream holds by then).
+        // The operations are frr_exchange_plan's: a pure function of (window, partition, rank), tested for every rank of
+        // worlds 2, 4 and 8 without that many GPUs (tests/test_multigpu_gloo.py)
+        frr_xfer ops[64];
+        const int nops = frr_exchange_plan(0, (int32_t)H, W, rank, world, /*blocked*/ 1, /*root*/ 0, ops, 64);
+        if (nops < 0 || nops > 64) { fprintf(stderr, "frr_exchange_plan: %d\n", nops); return 2; }
         CHECK_NCCL(ncclGroupStart());
-        int32_t r0 = 0, r1 = 0;
-        const bool own = frr_owned_band_count(ctx, 0, (int32_t)H) == 1 && frr_owned_rows(ctx, 0, (int32_t)H, 0, &r0, &r1) == FRR_OK;
-        if (rank != 0 && own) {
-            CHECK_NCCL(ncclSend((const float *)depth + (size_t)r0 * W, (size_t)(r1 - r0) * W, ncclFloat, 0, comm, stream));
-            CHECK_NCCL(ncclSend((const uint32_t *)ids + (size_t)r0 * W, (size_t)(r1 - r0) * W, ncclUint32, 0, comm, stream));
-        }
-        if (rank == 0) {
-            for (int p = 1; p < world; ++p) {
-                int32_t a = 0, b = 0;
-                if (frr_partition_rows(0, (int32_t)H, p, world, 1, 0, &a, &b) != 1) continue;   // a rank may own nothing (more ranks than tile rows)
-                CHECK_NCCL(ncclRecv(final_depth + (size_t)a * W, (size_t)(b - a) * W, ncclFloat, p, comm, stream));
-                CHECK_NCCL(ncclRecv(final_ids + (size_t)a * W, (size_t)(b - a) * W, ncclUint32, p, comm, stream));
+        for (int k = 0; k < nops; ++k) {
+            const frr_xfer &x = ops[k];
+            if (x.kind == FRR_XFER_SEND) {
+                CHECK_NCCL(ncclSend((const float *)depth + x.offset, x.count, ncclFloat, x.peer, comm, stream));
+                CHECK_NCCL(ncclSend((const uint32_t *)ids + x.offset, x.count, ncclUint32, x.peer, comm, stream));
+            } else if (x.kind == FRR_XFER_RECV) {
+                CHECK_NCCL(ncclRecv(final_depth + x.offset, x.count, ncclFloat, x.peer, comm, stream));
+                CHECK_NCCL(ncclRecv(final_ids + x.offset, x.count, ncclUint32, x.peer, comm, stream));
             }
         }
         CHECK_NCCL(ncclGroupEnd());
-        if (rank == 0 && own) {   // rank 0's own slab: a device copy
-            CHECK_HIP(hipMemcpyAsync(final_depth + (size_t)r0 * W, (const float *)depth + (size_t)r0 * W, (size_t)(r1 - r0) * W * 4, hipMemcpyDeviceToDevice, stream));
-            CHECK_HIP(hipMemcpyAsync(final_ids + (size_t)r0 * W, (const uint32_t *)ids + (size_t)r0 * W, (size_t)(r1 - r0) * W * 4, hipMemcpyDeviceToDevice, stream));
+        for (int k = 0; k < nops; ++k) {   // the root's own slab: a device copy
+            const frr_xfer &x = ops[k];
+            if (x.kind != FRR_XFER_COPY) continue;
+            CHECK_HIP(hipMemcpyAsync(final_depth + x.offset, (const float *)depth + x.offset, x.count * 4, hipMemcpyDeviceToDevice, stream));
+            CHECK_HIP(hipMemcpyAsync(final_ids + x.offset, (const uint32_t *)ids + x.offset, x.count * 4, hipMemcpyDeviceToDevice, stream));
         }
     }
-    CHECK_FRR(ctx, frr_sync(ctx));          // (also: a draw that needed a larger work list has been replayed by now)
+    CHECK_FRR(ctx, frr_sync(ctx));
     CHECK_HIP(hipStreamSynchronize(stream));
 
     int rc = 0;

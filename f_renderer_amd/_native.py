@@ -52,6 +52,10 @@ class SetupVertex(C.Structure):
     _fields_ = [("spf", C.c_float * 2), ("spi", C.c_int32 * 2), ("rhw", C.c_float), ("ctx", C.c_float * MAX_VARYINGS)]
 
 
+class Xfer(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("peer", C.c_int32), ("offset", C.c_uint64), ("count", C.c_uint64)]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("tris_in", C.c_uint64), ("tris_setup", C.c_uint64), ("bin_entries", C.c_uint64),
@@ -108,6 +112,7 @@ SIGNATURES = {
     "frr_owned_band_count": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "frr_owned_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
     "frr_partition_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
+    "frr_exchange_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, _P(Xfer), C.c_int]),
     "frr_set_count_fragments": (C.c_int, [C.c_void_p, C.c_int]),
     "frr_bind_targets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frr_target_ptrs": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_void_p)]),
@@ -125,6 +130,7 @@ SIGNATURES = {
     "frr_raster": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "frr_draw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "frr_frame_fence": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "frr_frame_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "frr_sync": (C.c_int, [C.c_void_p]),
     "frr_readback": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "frr_readback_setup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, _P(C.c_uint64)]),

@@ -151,6 +151,7 @@ struct FrameState {
     bool scan_pending = false;     // its block sums are not scanned yet (geom_scan: by the binning launch, or k_geom_scan)
     int geom_vs = -1;              // VS of the latest frr_geometry
     uint64_t geom_ntris = 0;
+    const float *geom_mesh = nullptr; uint64_t geom_duni_hash = 0;   // ... its mesh and (a digest of) its uniforms: DrawSig
 };
 
 struct Cmd {
@@ -166,6 +167,19 @@ struct Cmd {
     int set = 0;               // RASTER: the BinSet it ran with
     int lane = 0;              // the lane of device tables it ran in
 };
+
+// What decides how much of the work lists (fan space, (triangle, tile) records) a raster pass and its geometry pass need.
+struct DrawSig {
+    const float *mesh; uint64_t ntris; uint64_t duni_hash; uint32_t join_epoch;
+    int32_t vs, x0, x1, y0, y1, rank, world, blocked, filter, fy0, fy1, gset, bset;
+};
+inline bool same_sig(const DrawSig &a, const DrawSig &b) { return memcmp(&a, &b, sizeof a) == 0; }
+inline uint64_t fnv1a(const void *p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) h = (h ^ ((const unsigned char *)p)[i]) * 1099511628211ull;
+    return h;
+}
 
 } // namespace
 
@@ -211,6 +225,22 @@ struct frr_ctx {
     Counters hc;                    // host copy of the device counters as of the latest finish()
     uint32_t *host_bad = nullptr;   // host-visible word the device writes a failed command's number to (Counters::host_bad)
     uint32_t seen_bad = SEQ_NONE;   // its value when the host last looked
+    // A draw cannot fail, whoever consumes its targets and however (stream order, frr_frame_fence, frr_sync): a raster pass whose
+    // need of the work lists is not known to fit -- no pass with the same DrawSig has completed on the current lists -- is
+    // VERIFIED before frr_raster returns: the host waits for the pass's binning launch (not for its tile kernel), looks at
+    // host_bad, and repairs (finish(): grow + replay) if the pass or its geometry overflowed.  A proven pass is not waited for.
+    std::vector<DrawSig> proven;
+    hipEvent_t ev_verify = nullptr;
+    bool verify_pending = false;
+    DrawSig verify_sig;
+    // own targets handed out (frr_target_ptrs / frr_frame_fence): the frame that next renders into that set waits for what
+    // the stream they were handed to holds by then (the caller's reads), see frr_clear
+    bool exported[2] = {false, false};
+    hipStream_t export_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_export = nullptr;
+    // frr_frame_wait: the next kernel that writes the frame targets waits for this event
+    hipEvent_t ev_wait = nullptr;
+    bool wait_pending = false;
     size_t fan_hint = 0;       // fan capacity asked for by a draw that overflowed
     int bin_g = 0;             // option bin_chunks: override the number of binning chunks (dev)
     uint32_t ent_slot_override = 0; // option tile_slot_records: per-tile slot of bins2 in records (tests of the overflow arena)
@@ -280,6 +310,18 @@ hipStream_t tstream_of(const frr_ctx *c)
 hipStream_t gstream_of(const frr_ctx *c) { return c->fs.on_g ? c->gstream : tstream_of(c); }
 // do passes ever run beside each other on this ctx (workspace sets then carry events)?
 bool multi_stream(const frr_ctx *c) { return c->g_used || c->tstream2 != nullptr || c->tstream1 != nullptr; }
+
+// the ctx's own target set t (the second one is allocated on first use)
+int ensure_own_set(frr_ctx *c, int t)
+{
+    if (c->own_color[t] && c->own_depth[t] && c->own_tri_id[t]) return FRR_OK;
+    const size_t npx = (size_t)c->W * c->H;
+    const bool ok = (c->own_color[t] || hipMalloc((void **)&c->own_color[t], npx * 4) == hipSuccess) &&
+                    (c->own_depth[t] || hipMalloc((void **)&c->own_depth[t], npx * 4) == hipSuccess) &&
+                    (c->own_tri_id[t] || hipMalloc((void **)&c->own_tri_id[t], npx * 4) == hipSuccess);
+    if (!ok) return fail(c, FRR_ERR_NOMEM, "second target set");
+    return FRR_OK;
+}
 
 // all streams idle
 int drain(frr_ctx *c)
@@ -568,6 +610,7 @@ int clear_now(frr_ctx *c, uint32_t packed, float depth)
     hipStream_t ts = tstream_of(c);
     if (ts == c->tstream2) c->t2_dirty = c->t2_xdirty = true;
     if (ts == c->tstream1) c->t1_dirty = c->t1_xdirty = true;
+    if (c->wait_pending) { HIP_TRY(c, hipStreamWaitEvent(ts, c->ev_wait, 0)); c->wait_pending = false; }   // frr_frame_wait
     {
         ProfScope p(c, KID_CLEAR, ts);
         uint32_t grid = std::min<uint32_t>((n4 + 255) / 256, 2048);
@@ -696,6 +739,8 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
     f.geom_nblocks = nblocks;
     f.geom_seq = cmd.seq;
     f.geom_vs = m.vs; f.geom_ntris = nt;
+    f.geom_mesh = m.dev;   // (the uniforms' float fields: the struct has padding in front of its texture pointer)
+    f.geom_duni_hash = fnv1a(&cmd.duni, offsetof(DevUniforms, flat_color) + sizeof cmd.duni.flat_color) ^ (fnv1a(cmd.duni.user, sizeof cmd.duni.user) * 31u);
     f.tris_in += nt; f.draws += 1;
     if (nt == 0) {
         hipLaunchKernelGGL(k_geom_empty, dim3(1), dim3(64), 0, gstream_of(c), g);
@@ -816,7 +861,27 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
     }
     cmd.par = q; cmd.set = bi; cmd.lane = f.lane;
     HIP_TRY(c, hipGetLastError());
+    if (!c->in_replay) {
+        // does this pass's need of the work lists fit for sure?  (exec_cmd waits for the event if not: frr_ctx::proven)
+        DrawSig sig;
+        memset(&sig, 0, sizeof sig);
+        sig.mesh = f.geom_mesh; sig.ntris = f.geom_ntris; sig.duni_hash = f.geom_duni_hash; sig.join_epoch = c->join_epoch;
+        sig.vs = f.geom_vs; sig.x0 = x0; sig.x1 = x1; sig.y0 = y0; sig.y1 = y1; sig.rank = f.rank; sig.world = f.world;
+        sig.blocked = f.part_blocked ? 1 : 0; sig.filter = f.geom_filter.active ? 1 : 0; sig.fy0 = f.geom_filter.y0; sig.fy1 = f.geom_filter.y1;
+        sig.gset = f.gset; sig.bset = bi;
+        bool known = false;
+        for (const DrawSig &p : c->proven) known = known || same_sig(p, sig);
+        if (!known) {
+            HIP_TRY(c, hipEventRecord(c->ev_verify, gs));
+            c->verify_pending = true;
+            c->verify_sig = sig;
+        }
+    }
     if ((rc = tstream_wait_gstream(c)) != FRR_OK) return rc;   // the tile kernel runs on the targets' stream, after the binning
+    if (c->wait_pending) {   // frr_frame_wait: the targets' next writer follows what the caller's stream held
+        HIP_TRY(c, hipStreamWaitEvent(tstream_of(c), c->ev_wait, 0));
+        c->wait_pending = false;
+    }
     if (grid && um) {
         hipStream_t ts = tstream_of(c);
         ProfScope p(c, KID_RASTER, ts);
@@ -854,9 +919,25 @@ int exec_cmd(frr_ctx *c, Cmd cmd)
 {
     cmd.pre = c->fs;
     cmd.seq = c->next_seq++;
+    c->verify_pending = false;
     const int rc = cmd.kind == Cmd::GEOM ? exec_geometry(c, cmd) : exec_raster(c, cmd);
-    if (rc != FRR_OK) { c->fs = cmd.pre; return rc; }
+    if (rc != FRR_OK) { c->fs = cmd.pre; c->verify_pending = false; return rc; }
     c->log.push_back(cmd);
+    if (c->verify_pending) {
+        // An unproven raster pass: wait for its binning launch (the tile kernel behind it is not waited for: it cancels itself
+        // if the pass or its geometry found a list too small), then look at the word failed commands write to host memory.
+        c->verify_pending = false;
+        const DrawSig sig = c->verify_sig;
+        bool failed = true;   // (no host-visible word: a full synchronisation point decides)
+        if (c->host_bad) {
+            HIP_TRY(c, hipEventSynchronize(c->ev_verify));
+            failed = *(volatile uint32_t *)c->host_bad != c->seen_bad;
+        }
+        if (failed) { const int rf = finish(c); if (rf != FRR_OK) return rf; }   // grows the lists and replays, as often as it takes
+        if (c->proven.size() >= 32) c->proven.erase(c->proven.begin());
+        c->proven.push_back(sig);
+        return FRR_OK;
+    }
     if (c->log.size() >= 4096 && !c->in_replay) return finish(c);   // (a caller that never synchronises: bound the log)
     return FRR_OK;
 }
@@ -1006,6 +1087,8 @@ int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ct
     ok = ok && hipEventCreateWithFlags(&c->ev_t2, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming) == hipSuccess;
     for (auto &e : c->ev_bin) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_verify, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_export, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_wait, hipEventDisableTiming) == hipSuccess;
     if (!ok) { frr_destroy(c); return FRR_ERR_NOMEM; }
     c->fs.color = c->own_color[0]; c->fs.depth = c->own_depth[0]; c->fs.tri_id = c->own_tri_id[0];
     {
@@ -1065,6 +1148,7 @@ void frr_destroy(frr_ctx *c)
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     for (auto &e : c->ev_bin) if (e) (void)hipEventDestroy(e);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (hipEvent_t e : {c->ev_verify, c->ev_export, c->ev_wait}) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     // (back to the pool in the reverse order of their typical acquisition, so that the next ctx gets them in the same roles)
     release_stream(c->device, c->gstream);
@@ -1078,6 +1162,7 @@ int frr_set_option(frr_ctx *c, const char *name, int64_t v)
 {
     if (!c || !name) return FRR_ERR_INVALID;
     { int rc = finish(c); if (rc != FRR_OK) return rc; }   // nothing in flight, nothing to replay under the old setting
+    c->proven.clear();                                     // (options change what a pass needs of the lists, or the lists)
     const std::string n(name);
     if (n == "raster_sweep") c->raster_sweep = v != 0;
     else if (n == "raster_nw") { if (v != 0 && v != LIGHT_NW && v != 4 && v != 6 && v != 8 && v != 16) return fail(c, FRR_ERR_INVALID, "raster_nw: 0, 3, 4, 6, 8 or 16"); c->raster_nw = (int)v; }
@@ -1141,6 +1226,28 @@ int frr_partition_rows(int32_t y0, int32_t y1, int rank, int world, int blocked,
     if (y0 > y1 || world < 1 || rank < 0 || rank >= world || band < 0 || (row0 == nullptr) != (row1 == nullptr)) return FRR_ERR_INVALID;
     return owned_band_of(rank, world, blocked != 0, (int64_t)y1 - y0, band, row0, row1);
 }
+int frr_exchange_plan(int32_t y0, int32_t y1, uint32_t row_elems, int rank, int world, int blocked, int root, frr_xfer *ops, int cap)
+{
+    if (y0 > y1 || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || cap < 0 || (cap && !ops)) return FRR_ERR_INVALID;
+    const int64_t wh = (int64_t)y1 - y0;
+    int n = 0;
+    auto put = [&](int kind, int peer, int32_t r0, int32_t r1) {
+        if (n < cap) ops[n] = frr_xfer{kind, peer, (uint64_t)r0 * row_elems, (uint64_t)(r1 - r0) * row_elems};
+        ++n;
+    };
+    auto bands_of = [&](int p, int kind, int peer) {
+        const int nb = owned_band_of(p, world, blocked != 0, wh, 0, nullptr, nullptr);
+        for (int b = 0; b < nb; ++b) {
+            int32_t r0 = 0, r1 = 0;
+            (void)owned_band_of(p, world, blocked != 0, wh, b, &r0, &r1);
+            if (r1 > r0) put(kind, peer, r0, r1);
+        }
+    };
+    if (rank != root) { bands_of(rank, FRR_XFER_SEND, root); return n; }
+    for (int p = 0; p < world; ++p) if (p != root) bands_of(p, FRR_XFER_RECV, p);
+    bands_of(root, FRR_XFER_COPY, root);
+    return n;
+}
 int frr_owned_band_count(const frr_ctx *c, int32_t y0, int32_t y1)
 {
     if (!c || y0 > y1) return FRR_ERR_INVALID;
@@ -1166,7 +1273,15 @@ int frr_bind_targets(frr_ctx *c, void *color, void *depth, void *tri_id)
 {
     if (!c) return FRR_ERR_INVALID;
     { int rc = settle(c); if (rc != FRR_OK) return rc; } // a pending clear belongs to the targets bound when it was issued
+    if (c->bound_in_flight && (!color || !depth || !tri_id) && (color || depth || tri_id))
+        return fail(c, FRR_ERR_INVALID, "option bound_targets_in_flight: bind all three targets, or none (back to the ctx's own)");
     if (!(c->bound_in_flight && !own_targets(c))) { int rc = join_tile_streams(c); if (rc != FRR_OK) return rc; }   // (frames in flight on bound targets: the caller fences)
+    if (!color || !depth || !tri_id) {
+        // (part of) the ctx's own set: frames on bound targets may have toggled the set index without it ever being allocated
+        if (c->bound_in_flight) { int rc = finish(c); if (rc != FRR_OK) return rc; }   // back to own targets: nothing of the bound frames in flight
+        int rc = ensure_own_set(c, c->fs.tset);
+        if (rc != FRR_OK) return rc;
+    }
     c->fs.color = color ? (uint8_t *)color : c->own_color[c->fs.tset];
     c->fs.depth = depth ? (float *)depth : c->own_depth[c->fs.tset];
     c->fs.tri_id = tri_id ? (uint32_t *)tri_id : c->own_tri_id[c->fs.tset];
@@ -1177,6 +1292,7 @@ int frr_target_ptrs(frr_ctx *c, void **color, void **depth, void **tri_id)
     if (!c) return FRR_ERR_INVALID;
     { int rc = settle(c); if (rc != FRR_OK) return rc; } // the caller is about to look at them ...
     { int rc = join_tile_streams(c); if (rc != FRR_OK) return rc; } // ... from its stream
+    if (own_targets(c)) { c->exported[c->fs.tset] = true; c->export_stream[c->fs.tset] = c->stream; }   // (frr_clear orders the set's next frame behind those reads)
     if (color) *color = c->fs.color;
     if (depth) *depth = c->fs.depth;
     if (tri_id) *tri_id = c->fs.tri_id;
@@ -1333,13 +1449,8 @@ int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
         // own targets: this frame takes the other set (and its tile kernels the other stream), so that it need not wait
         // for the previous frame's tile kernel to drain; the old set's content is dead (the clear overwrites everything)
         const int t = f.tset ^ 1;
-        if (!c->own_color[t]) {
-            const size_t npx = (size_t)c->W * c->H;
-            bool ok = hipMalloc((void **)&c->own_color[t], npx * 4) == hipSuccess && hipMalloc((void **)&c->own_depth[t], npx * 4) == hipSuccess &&
-                      hipMalloc((void **)&c->own_tri_id[t], npx * 4) == hipSuccess;
-            ok = ok && (c->tstream2 || acquire_stream(c->device, &c->tstream2) == hipSuccess);
-            if (!ok) return fail(c, FRR_ERR_NOMEM, "second target set");
-        }
+        { const int rc = ensure_own_set(c, t); if (rc != FRR_OK) return rc; }
+        if (!c->tstream2 && acquire_stream(c->device, &c->tstream2) != hipSuccess) return fail(c, FRR_ERR_HIP, "frame stream");
         f.tset = t;
         f.color = c->own_color[t]; f.depth = c->own_depth[t]; f.tri_id = c->own_tri_id[t];
         f.lane = t;    // ... and its own device tables: nothing the two frames' bookkeeping threads write is shared
@@ -1353,6 +1464,17 @@ int frr_clear(frr_ctx *c, const uint8_t rgba[4], float depth)
         f.lane = f.tset;
     } else {
         f.lane = 0;
+    }
+    if (own_targets(c) && c->exported[f.tset]) {
+        // The pointers of this own target set were handed out (frr_target_ptrs / frr_frame_fence) when it last held a frame:
+        // what the caller has queued on that stream since -- its reads of that frame -- comes before this frame's writes.
+        // (Same stream: in order anyway.  Only callers that take the pointers pay for the event.)
+        c->exported[f.tset] = false;
+        hipStream_t ts = tstream_of(c);
+        if (c->export_stream[f.tset] != ts) {
+            HIP_TRY(c, hipEventRecord(c->ev_export, c->export_stream[f.tset]));
+            HIP_TRY(c, hipStreamWaitEvent(ts, c->ev_export, 0));
+        }
     }
     if (c->clear_eager) { f.clear_pending = false; return clear_now(c, packed, depth); }
     f.clear_rgba = packed; f.clear_depth = depth;
@@ -1437,7 +1559,18 @@ int frr_frame_fence(frr_ctx *c, void *stream)
     if (!c) return FRR_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     { int rc = settle(c); if (rc != FRR_OK) return rc; }
-    return fence_stream(c, stream ? (hipStream_t)stream : c->stream);
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (own_targets(c)) { c->exported[c->fs.tset] = true; c->export_stream[c->fs.tset] = st; }
+    return fence_stream(c, st);
+}
+
+int frr_frame_wait(frr_ctx *c, void *stream)
+{
+    if (!c) return FRR_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(c->ev_wait, stream ? (hipStream_t)stream : c->stream));
+    c->wait_pending = true;
+    return FRR_OK;
 }
 
 int frr_sync(frr_ctx *c)

@@ -148,8 +148,11 @@ class BlockGather:
         t0 = time.perf_counter()
         for h in handles:
             while not h.is_completed():
-                if time.perf_counter() - t0 > 2.0:   # never expected; fall back to the stream-side wait rather than spin forever
+                if time.perf_counter() - t0 > 2.0:   # never expected; fall back to a full wait rather than spin forever
                     h.wait()
+                    import torch
+                    if torch.cuda.is_available():
+                        torch.cuda.current_stream().synchronize()   # (callers rely on HOST-visible completion: bench.py re-binds the set)
                     break
         return self.final
 

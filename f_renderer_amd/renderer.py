@@ -294,6 +294,11 @@ class Renderer:
         issued so far -- no host wait (frr_frame_fence; option bound_targets_in_flight)."""
         self._check(self._lib.frr_frame_fence(self._ctx, C.c_void_p(stream or 0)))
 
+    def frame_wait(self, stream=None):
+        """The next kernel that writes the frame targets waits for what `stream` (default: the ctx's) holds now
+        (frr_frame_wait): e.g. an exchange that still reads a target set about to be bound for a new frame."""
+        self._check(self._lib.frr_frame_wait(self._ctx, C.c_void_p(stream or 0)))
+
     def sync(self):
         self._check(self._lib.frr_sync(self._ctx))
 

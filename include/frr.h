@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FRR_ABI_VERSION 3
+#define FRR_ABI_VERSION 4
 #define FRR_MAX_VARYINGS 16
 #define FRR_MAX_TEXTURES 4
 #define FRR_MAX_USER_UNIFORMS 32 /* f32 a user shader receives (frr_set_user_uniforms) */
@@ -140,8 +140,11 @@ typedef struct frr_stats {
  * (tile kernels, clears, read-backs) runs on it, in call order.  The ctx owns a second, private stream on which the
  * geometry and binning kernels of the next draw run beside the tile kernel of the current one (option "overlap");
  * it is ordered against `stream` with events, so the caller sees one in-order queue -- with one rule: the contents of
- * a device-bound mesh (frr_mesh_bind_device) are read some time between the frr_draw call and the draw's tile kernel,
- * so a caller that rewrites such a mesh in place on `stream` binds it again (or calls frr_sync) before the next draw. */
+ * a device-bound mesh (frr_mesh_bind_device) are read some time between the frr_draw call and the end of the frame's
+ * tile kernels, on the library's streams.  A caller that rewrites such a mesh in place therefore (1) orders the rewrite
+ * BEHIND the draws issued so far -- frr_frame_fence(ctx, the stream it rewrites on) -- and (2) binds the mesh again
+ * (frr_mesh_bind_device: the library's streams then wait for that stream once) before the next draw.  frr_sync in place
+ * of (1) and (2) is always sufficient. */
 int frr_create(int device, uint32_t width, uint32_t height, void *stream, frr_ctx **out);
 void frr_destroy(frr_ctx *ctx);
 const char *frr_last_error(const frr_ctx *ctx);
@@ -168,17 +171,38 @@ int frr_owned_rows(const frr_ctx *ctx, int32_t y0, int32_t y1, int32_t band, int
  * (examples/gather_rccl.cpp).  Returns the number of bands rank `rank` of `world` owns in a window of height_range
  * (y0, y1) (negative: bad argument); if row0/row1 are not NULL and band is in range they receive band `band`. */
 int frr_partition_rows(int32_t y0, int32_t y1, int rank, int world, int blocked, int32_t band, int32_t *row0, int32_t *row1);
+/* The final-image exchange of one plane as a list of operations -- a pure function of (window, partition, rank), no ctx and
+ * no device: what examples/gather_rccl.cpp posts inside one ncclGroupStart / ncclGroupEnd per frame, and what a test can
+ * check for every rank of any world size without owning that many GPUs.  The plane is row-major with `row_elems` elements
+ * per pixel row; offsets and counts are in elements.  For rank `rank`: on a rank other than `root` one FRR_XFER_SEND per
+ * owned band (to root); on root one FRR_XFER_RECV per owned band of every other rank, and one FRR_XFER_COPY per band of its
+ * own (render target -> final image, a device copy).  Every element of the window's plane is the destination of exactly
+ * one RECV or COPY of root's list, and each SEND of rank p equals (offset, count) the RECV root posts for p, in the same
+ * order.  Returns the number of operations (written up to `cap`), or a negative frr_status. */
+typedef enum frr_xfer_kind { FRR_XFER_SEND = 0, FRR_XFER_RECV = 1, FRR_XFER_COPY = 2 } frr_xfer_kind;
+typedef struct frr_xfer {
+    int32_t kind;     /* frr_xfer_kind */
+    int32_t peer;     /* SEND: root; RECV: the sending rank; COPY: root itself */
+    uint64_t offset;  /* first element, in the rank's render target AND in the final image (same layout) */
+    uint64_t count;   /* elements */
+} frr_xfer;
+int frr_exchange_plan(int32_t y0, int32_t y1, uint32_t row_elems, int rank, int world, int blocked, int root, frr_xfer *ops, int cap);
 /* frr_stats.frag_covered is exact while counting is enabled (default).  Disabling it lets the tile
  * kernel drop whole triangles by hierarchical early-z before their coverage is known (images are
  * identical either way; only the statistic stops being maintained). */
 int frr_set_count_fragments(frr_ctx *ctx, int enable);
 
 /* Use caller-owned DEVICE buffers (e.g. torch tensors) as the frame targets instead of the
- * internally allocated ones; any may be NULL to keep the internal one.  On a partitioned ctx
+ * internally allocated ones; any may be NULL to keep the internal one (with option bound_targets_in_flight: all three
+ * or none).  On a partitioned ctx
  * (frr_set_partition, world > 1) only the tile rows the rank owns are defined in caller-owned targets
  * (a clear that was performed inside a draw never touches the other ranks' rows); the ctx's own targets
  * are brought up to date in full whenever they are read back. */
 int frr_bind_targets(frr_ctx *ctx, void *color_rgba8, void *depth_f32, void *tri_id_u32);
+/* The device pointers of the current frame's targets, for reads queued on the ctx's stream (which first waits for the
+ * frames issued so far).  With two frames in flight the ctx's own targets are two sets: the pointers are those of the
+ * CURRENT frame and stay that frame's until the second frr_clear from now, which -- like every frr_clear that reuses a
+ * set whose pointers were handed out -- orders the new frame behind what that stream holds by then (the caller's reads). */
 int frr_target_ptrs(frr_ctx *ctx, void **color_rgba8, void **depth_f32, void **tri_id_u32);
 
 /* ---- scene ------------------------------------------------------------------------------- */
@@ -223,11 +247,20 @@ int frr_raster(frr_ctx *ctx, int ps_id, int32_t x0, int32_t x1, int32_t y0, int3
 int frr_draw(frr_ctx *ctx, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t y0, int32_t y1);
 
 /* Stream-side fence, no host wait: `stream` (a hipStream_t of the caller; NULL = the ctx's stream) waits for every frame
- * issued so far, so that what the caller enqueues on it next sees their targets.  Needed only with option
- * bound_targets_in_flight (below): without it everything that touches caller-bound targets runs on the ctx's stream anyway.
- * A draw that needs a larger work list is replayed at the next synchronisation point, not here: callers that consume targets
- * through fences alone should size the lists once (a warm-up frame followed by frr_sync does). */
+ * issued so far, so that what the caller enqueues on it next sees their targets.  Needed with option bound_targets_in_flight
+ * (below) and by callers that read the ctx's own targets (frr_target_ptrs) on a stream other than the ctx's; also the way to
+ * order an in-place rewrite of a device-bound mesh behind the draws that still read it (frr_create).
+ * The frames it fences are whole: like the reference's draw (renderer.rs:269-384 has no failure path) a draw of this
+ * library cannot fail -- a raster pass whose need of the internal work lists is not known to fit is checked on the host,
+ * and repaired, before frr_raster / frr_draw returns (the call then waits for the pass's binning launch, not for its tile
+ * kernel; a pass that repeats a mesh, uniforms, window and partition already seen to fit is not waited for). */
 int frr_frame_fence(frr_ctx *ctx, void *stream);
+/* The reverse edge: the next kernel that WRITES the frame targets (the pending frr_clear, the next tile kernel) waits for
+ * what `stream` (NULL = the ctx's stream) holds now -- e.g. an exchange that still reads a caller-bound target set which is
+ * about to be bound for a new frame under option bound_targets_in_flight, where no frame work runs on the ctx's stream.
+ * (The ctx's OWN targets need no such call: the library orders a set's next frame behind whatever was queued on the stream
+ * the set's pointers were handed to by frr_target_ptrs / frr_frame_fence, up to the frr_clear that starts that frame.) */
+int frr_frame_wait(frr_ctx *ctx, void *stream);
 /* Synchronisation point: waits for everything issued so far (both streams).  Caller-bound targets are defined, and a
  * draw that needed a larger work list has been replayed (FRR_ERR_CAPACITY), when this -- or frr_readback,
  * frr_get_stats, frr_readback_setup, frr_geometry with a count -- returns. */

@@ -48,6 +48,15 @@ pub mod ffi {
         pub replays: u32,
     }
 
+    #[repr(C)]
+    #[derive(Clone, Copy, Default, Debug)]
+    pub struct frr_xfer {
+        pub kind: i32,
+        pub peer: i32,
+        pub offset: u64,
+        pub count: u64,
+    }
+
     extern "C" {
         pub fn frr_abi_version() -> c_int;
         pub fn frr_create(device: c_int, width: u32, height: u32, stream: *mut c_void, out: *mut *mut frr_ctx) -> c_int;
@@ -67,6 +76,8 @@ pub mod ffi {
         pub fn frr_shader_register(ctx: *mut frr_ctx, hip_source: *const c_char, vs_input_floats: c_int, num_varyings: c_int, shader_id: *mut c_int) -> c_int;
         pub fn frr_set_user_uniforms(ctx: *mut frr_ctx, values: *const f32, n: c_int) -> c_int;
         pub fn frr_frame_fence(ctx: *mut frr_ctx, stream: *mut c_void) -> c_int;
+        pub fn frr_frame_wait(ctx: *mut frr_ctx, stream: *mut c_void) -> c_int;
+        pub fn frr_exchange_plan(y0: i32, y1: i32, row_elems: u32, rank: c_int, world: c_int, blocked: c_int, root: c_int, ops: *mut frr_xfer, cap: c_int) -> c_int;
         pub fn frr_partition_rows(y0: i32, y1: i32, rank: c_int, world: c_int, blocked: c_int, band: i32, row0: *mut i32, row1: *mut i32) -> c_int;
         pub fn frr_clear(ctx: *mut frr_ctx, rgba: *const u8, depth: f32) -> c_int;
         pub fn frr_geometry(ctx: *mut frr_ctx, mesh: c_int, ntris_setup: *mut u64) -> c_int;

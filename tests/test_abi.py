@@ -25,7 +25,7 @@ def test_header_symbols_all_exported():
     for s in syms:
         assert hasattr(L, s), f"libfrr_hip.so does not export {s}"
     assert set(syms) == set(_native.SIGNATURES), "ctypes binding and include/frr.h disagree"
-    assert fr.lib().frr_abi_version() == 3
+    assert fr.lib().frr_abi_version() == 4
 
 
 def test_struct_layouts_match_header():

@@ -124,3 +124,44 @@ def test_band_layout_matches_partition_rule():
             assert rows == list(range(tiles_y))                # every tile row has exactly one owner
             for r in range(world):
                 assert all(ty % world == r for ty in owned_tile_rows(H, r, world))   # frr_set_partition's rule
+
+
+def test_exchange_plan_of_every_rank_without_gpus():
+    """frr_exchange_plan (the operations examples/gather_rccl.cpp posts per frame) for every rank of worlds 2, 4 and 8 --
+    also 3 and 40, more ranks than tile rows -- and both layouts: every sender's operations are the receives the root posts
+    for it, the root's receives + own copies tile the plane exactly once, and the blocked plan is multigpu.block_rows'."""
+    import ctypes as C
+    import f_renderer_amd as fr
+    from f_renderer_amd import _native as N
+    from f_renderer_amd.multigpu import block_rows
+    L = fr.lib()
+    SEND, RECV, COPY = 0, 1, 2
+
+    def plan(H, W, rank, world, blocked, root=0):
+        ops = (N.Xfer * 256)()
+        n = L.frr_exchange_plan(0, H, W, rank, world, blocked, root, ops, 256)
+        assert 0 <= n <= 256
+        return [(ops[i].kind, ops[i].peer, ops[i].offset, ops[i].count) for i in range(n)]
+
+    for H, W in ((1080, 1920), (4096, 4096), (2160, 3840), (500, 640), (33, 7)):
+        for world in (1, 2, 3, 4, 8, 40):
+            for blocked in (1, 0):
+                for root in ({0, world - 1} if world > 1 else {0}):
+                    rootp = plan(H, W, root, world, blocked, root)
+                    covered = np.zeros(H * W, np.uint8)
+                    for kind, peer, off, cnt in rootp:
+                        assert kind in (RECV, COPY) and (peer == root) == (kind == COPY)
+                        covered[off:off + cnt] += 1
+                    assert covered.min() == 1 and covered.max() == 1, (H, W, world, blocked)
+                    for r in range(world):
+                        if r == root:
+                            continue
+                        mine = plan(H, W, r, world, blocked, root)
+                        assert all(k == SEND and p == root for k, p, _, _ in mine)
+                        assert [(o, c) for _, _, o, c in mine] == [(o, c) for k, p, o, c in rootp if k == RECV and p == r]
+                        if blocked:
+                            a, b = block_rows(H, r, world)
+                            b = min(b, H)
+                            assert [(o, c) for _, _, o, c in mine] == ([(a * W, (b - a) * W)] if b > a else [])
+    assert L.frr_exchange_plan(0, 100, 10, 2, 2, 1, 0, None, 0) < 0      # rank out of range
+    assert L.frr_exchange_plan(0, 1080, 1920, 3, 8, 1, 0, None, 0) == 1  # counting only
