@@ -488,6 +488,7 @@ void refresh_dev_uniforms(frr_ctx *c)
     int s = c->uni.texture_slot;
     if (s >= 0 && s < FRR_MAX_TEXTURES) { d.tex = c->tex[s].dev; d.tex_w = c->tex[s].w; d.tex_h = c->tex[s].h; }
     else { d.tex = nullptr; d.tex_w = d.tex_h = 0; }
+    for (int k = 0; k < FRR_MAX_TEXTURES; ++k) { d.slot_tex[k] = c->tex[k].dev; d.slot_w[k] = c->tex[k].w; d.slot_h[k] = c->tex[k].h; }
 }
 
 // Tile rows [t0, t1) of rank `rank` in the blocked layout: the first tiles_y % world ranks own one row more than the
@@ -1509,8 +1510,12 @@ static int raster_check(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y
     if (ww > 0 && wh > 0 && (x1 <= 0 || (wh - 1) * (int64_t)x1 + ww > (int64_t)c->W * c->H))
         return fail(c, FRR_ERR_INVALID, "depth index (cy-y0)*x1+(cx-x0) would leave the depth buffer (renderer.rs:362)");
     const int K = frr_vs_num_varyings(f.geom_vs);
-    if (ps_id >= FRR_SHADER_USER_BASE || f.geom_vs >= FRR_SHADER_USER_BASE) {
-        if (ps_id != f.geom_vs || !user_shader(ps_id)) return fail(c, FRR_ERR_INVALID, "a user shader id stands for its vertex AND pixel shader: draw the mesh with the id it was uploaded with");
+    if (ps_id >= FRR_SHADER_USER_BASE) {
+        // a user pixel shader: the mesh's vertex shader -- the same user shader, another one, or a built-in -- has to hand it
+        // the varyings it was registered with (the reference's two closures share one ShaderContext type, renderer.rs:97-110)
+        const UserShader *us = user_shader(ps_id);
+        if (!us) return fail(c, FRR_ERR_INVALID, "unknown shader id");
+        if (us->K != K) return fail(c, FRR_ERR_INVALID, "the user pixel shader's varyings do not match the vertex shader's");
         if (c->raster_sweep) return fail(c, FRR_ERR_UNSUPPORTED, "the brute-force tile kernel (option raster_sweep) is not generated for user shaders");
     } else if ((ps_id == FRR_PS_COLOR && K != 3) || ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && K != 8) || ps_id < 0 || ps_id > FRR_PS_BLINN)
         return fail(c, FRR_ERR_INVALID, "pixel shader does not match the vertex shader's varyings");

@@ -151,9 +151,13 @@ struct DevUniforms {
     float light_color[3];
     float ambient_strength, specular_strength;
     float flat_color[4];
-    const uint8_t *tex;
+    const uint8_t *tex;                  // the texture in uniforms.texture_slot (PSUniform.place, phong.rs:34-38,147-151)
     uint32_t tex_w, tex_h;
     float user[FRR_MAX_USER_UNIFORMS];   // frr_set_user_uniforms: what a user shader's closure would have captured
+    // every texture slot (PSUniform holds three textures, phong.rs:41-47, and a closure may sample any of them:
+    // sample_2d_slot); null / 0 x 0 where nothing was uploaded
+    const uint8_t *slot_tex[FRR_MAX_TEXTURES];
+    uint32_t slot_w[FRR_MAX_TEXTURES], slot_h[FRR_MAX_TEXTURES];
 };
 
 struct GeomArgs {
@@ -547,20 +551,20 @@ __device__ __forceinline__ Frag frag_eval(float s0x_, float s0y_, float s1x_, fl
 // FrameBuffer::sample_2d renderer.rs:516-538 (+ get_pixel :505-514, u8_array_to_vec4 :16-24)
 // u8lut: optional 256-entry table of (float)i / 255.0f (the tile kernel keeps one in LDS: the 16 IEEE
 // divisions of a bilinear sample become 16 table reads of the very same quotients)
-__device__ __forceinline__ void sample_2d(const DevUniforms &u, float uu, float vv, float out[4], const float *u8lut = nullptr)
+__device__ __forceinline__ void sample_2d_of(const uint8_t *tex, uint32_t tex_w, uint32_t tex_h, float uu, float vv, float out[4], const float *u8lut = nullptr)
 {
-    float x = uu * (float)u.tex_w;
-    float y = vv * (float)u.tex_h;
+    float x = uu * (float)tex_w;
+    float y = vv * (float)tex_h;
     float a = x - truncf(x);
     float b = y - truncf(y);
-    uint32_t wm1 = u.tex_w - 1u;
+    uint32_t wm1 = tex_w - 1u;
     uint32_t x1 = min(f32_as_u32(x), wm1);
     uint32_t y1 = min(f32_as_u32(y), wm1); // sic: width (:523)
     uint32_t x2 = min(x1 + 1u, wm1);
     uint32_t y2 = min(y1 + 1u, wm1);       // sic: width (:525)
-    const uchar4 *t = reinterpret_cast<const uchar4 *>(u.tex);
-    uchar4 q11 = t[y1 * u.tex_w + x1], q12 = t[y2 * u.tex_w + x1];
-    uchar4 q21 = t[y1 * u.tex_w + x2], q22 = t[y2 * u.tex_w + x2];
+    const uchar4 *t = reinterpret_cast<const uchar4 *>(tex);
+    uchar4 q11 = t[y1 * tex_w + x1], q12 = t[y2 * tex_w + x1];
+    uchar4 q21 = t[y1 * tex_w + x2], q22 = t[y2 * tex_w + x2];
     float oma = 1.0f - a, omb = 1.0f - b;
     const uint8_t *p11 = reinterpret_cast<const uint8_t *>(&q11), *p12 = reinterpret_cast<const uint8_t *>(&q12);
     const uint8_t *p21 = reinterpret_cast<const uint8_t *>(&q21), *p22 = reinterpret_cast<const uint8_t *>(&q22);
@@ -578,6 +582,19 @@ __device__ __forceinline__ void sample_2d(const DevUniforms &u, float uu, float 
         float c22 = t22 * a * b;
         out[k] = c11 + c12 + c21 + c22;
     }
+}
+
+// the texture in uniforms.texture_slot ...
+__device__ __forceinline__ void sample_2d(const DevUniforms &u, float uu, float vv, float out[4], const float *u8lut = nullptr)
+{
+    sample_2d_of(u.tex, u.tex_w, u.tex_h, uu, vv, out, u8lut);
+}
+// ... or any slot by number (user shaders: a closure over PSUniform may sample each of its textures, phong.rs:41-47,147-151);
+// an empty slot samples as zero
+__device__ __forceinline__ void sample_2d_slot(const DevUniforms &u, int slot, float uu, float vv, float out[4], const float *u8lut = nullptr)
+{
+    if (slot < 0 || slot >= FRR_MAX_TEXTURES || !u.slot_tex[slot]) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+    sample_2d_of(u.slot_tex[slot], u.slot_w[slot], u.slot_h[slot], uu, vv, out, u8lut);
 }
 
 template <int PS>

@@ -84,14 +84,18 @@ typedef enum frr_ps {
  * u.mvp / u.model (column-major), u.view_pos, u.light_pos, u.light_color, u.ambient_strength, u.specular_strength,
  * u.flat_color, u.user[FRR_MAX_USER_UNIFORMS] (frr_set_user_uniforms: what the closure would have captured),
  * frr::mat4_mul_vec4, frr::dot3, frr::normalize3 (glam's operation order), frr::f32_max, frr::recip_exact, and
- * frr::sample_2d(u, uu, vv, rgba_out, u8lut) (FrameBuffer::sample_2d of the texture in uniforms.texture_slot, :516-538).
- * fp32 expressions keep their written association (no FMA contraction), as in the reference's Rust.
+ * frr::sample_2d(u, uu, vv, rgba_out, u8lut) (FrameBuffer::sample_2d of the texture in uniforms.texture_slot, :516-538) and
+ * frr::sample_2d_slot(u, slot, uu, vv, rgba_out, u8lut) (the same of ANY uploaded slot 0..FRR_MAX_TEXTURES-1: the
+ * reference's PSUniform holds three textures and its closure may sample each, phong.rs:41-47,147-151; an empty slot
+ * samples as zero).  fp32 expressions keep their written association (no FMA contraction), as in the reference's Rust.
  *
  * frr_shader_register returns one id >= FRR_SHADER_USER_BASE that stands for the pair: pass it as vs_id to
- * frr_mesh_upload / frr_mesh_bind_device and as ps_id to frr_raster / frr_draw of that mesh.  ctx may be NULL (compile
- * only: the registry is per process; a ctx loads the code object on first use).  A source that does not compile:
- * FRR_ERR_UNSUPPORTED, with the compiler's log in frr_last_error(ctx).  The brute-force tile kernel (option raster_sweep)
- * is not generated for user shaders. */
+ * frr_mesh_upload / frr_mesh_bind_device and as ps_id to frr_raster / frr_draw.  The two halves also combine with the
+ * tables: a mesh uploaded with a user id may be drawn with a built-in ps_id, and a mesh with a built-in (or another
+ * user) vs_id with a user ps_id -- provided the pixel shader's varyings are the vertex shader's (frr_vs_num_varyings;
+ * FRR_ERR_INVALID otherwise).  ctx may be NULL (compile only: the registry is per process; a ctx loads the code object
+ * on first use).  A source that does not compile: FRR_ERR_UNSUPPORTED, with the compiler's log in frr_last_error(ctx).
+ * The brute-force tile kernel (option raster_sweep) is not generated for user shaders. */
 int frr_shader_register(frr_ctx *ctx, const char *hip_source, int vs_input_floats, int num_varyings, int *shader_id);
 /* u.user[0..n) for the draws issued from now on (n <= FRR_MAX_USER_UNIFORMS; travels with each draw like frr_uniforms) */
 int frr_set_user_uniforms(frr_ctx *ctx, const float *values, int n);

@@ -153,8 +153,11 @@ def sample_2d(tex, uv):                                        # renderer.rs:516
 
 
 def pixel_shader(ps_id, u, ctx):
-    """ctx [n,K] -> rgba [n,4] (float32)"""
+    """ctx [n,K] -> rgba [n,4] (float32).  ps_id may be a callable (u, ctx) -> rgba: a closure written for one test, the way
+    the reference takes its pixel shader (renderer.rs:273,283)."""
     n = ctx.shape[0]
+    if callable(ps_id):
+        return np.asarray(ps_id(u, ctx), F)
     if ps_id == PS_FLAT:
         return np.broadcast_to(u.flat_color, (n, 4)).astype(F)
     if ps_id == PS_COLOR:

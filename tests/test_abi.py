@@ -114,6 +114,8 @@ def test_user_shader_text_compiles_without_a_gpu():
     sid = C.c_int(-1)
     assert L.frr_shader_register(None, user_shaders.VERTEX_COLOR.encode(), 7, 3, C.byref(sid)) == fr.FRR_OK
     assert sid.value >= 64 and L.frr_vs_input_floats(sid.value) == 7 and L.frr_vs_num_varyings(sid.value) == 3
+    two = C.c_int(-1)   # frr::sample_2d_slot: a closure over more than one texture
+    assert L.frr_shader_register(None, user_shaders.TWO_TEXTURES.encode(), 8, 8, C.byref(two)) == fr.FRR_OK and two.value > sid.value
     bad = C.c_int(-1)
     assert L.frr_shader_register(None, user_shaders.BROKEN.encode(), 4, 0, C.byref(bad)) == fr.FRR_ERR_UNSUPPORTED and bad.value == -1
     assert L.frr_shader_register(None, user_shaders.VERTEX_COLOR.encode(), 0, 3, C.byref(bad)) == fr.FRR_ERR_INVALID

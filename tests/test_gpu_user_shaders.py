@@ -127,7 +127,11 @@ def test_user_shader_errors():
     m = r.upload_mesh(scenes.random_clip_triangles(10, 64, 64, seed=1), sid)
     r.clear()
     with pytest.raises(fr.FrrError) as e:
-        r.draw(m, fr.PS_FLAT)                       # a user id stands for the pair
+        r.draw(m, fr.PS_COLOR)                      # the built-in pixel shader wants three varyings, this vertex shader has none
+    assert e.value.code == fr.FRR_ERR_INVALID
+    sid3 = r.register_shader(user_shaders.VERTEX_COLOR, 7, 3)
+    with pytest.raises(fr.FrrError) as e:
+        r.draw(m, sid3)                             # ... and so does this user pixel shader
     assert e.value.code == fr.FRR_ERR_INVALID
     r.set_option("raster_sweep", 1)
     with pytest.raises(fr.FrrError) as e:
@@ -136,3 +140,82 @@ def test_user_shader_errors():
     r.set_option("raster_sweep", 0)
     r.draw(m, sid)
     r.sync()
+
+
+def test_two_texture_user_pixel_shader_on_a_builtin_vertex_shader():
+    """A closure over more than one texture (PSUniform holds three, phong.rs:41-47): frr::sample_2d_slot.  The mesh keeps the
+    built-in VS_PHONG; the user pixel shader is held to a pixel shader written for this test on the NumPy oracle (the way the
+    reference takes its closures), bit for bit -- RGBA8, depth, ids."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    from oracle import oracle_np as onp
+    W, H = 200, 130
+    mesh = scenes.displaced_sphere(n=20)
+    texA = scenes.checker_texture(64, 8)
+    texB = np.ascontiguousarray(np.roll(scenes.checker_texture(32, 4), 5, axis=1)[:, :, [2, 1, 0, 3]])
+    eye, at, up, fovy, aspect, zn, zf = scenes.demo_camera(W, H)
+    wa, wb = np.float32(0.625), np.float32(0.3)
+
+    def ps(u, ctx):
+        a = onp.sample_2d(texA, ctx[:, 0:2])
+        b = onp.sample_2d(texB, ctx[:, [1, 0]])
+        return a * wa + b * wb
+
+    color = np.zeros((H, W, 4), np.uint8); color[:] = (30, 30, 30, 255)
+    depth = np.zeros(W * H, np.float32)
+    ids = np.full(W * H, 0xFFFFFFFF, np.uint32)
+    u = onp.Uniforms(view=onp.set_look_at(eye, at, up), proj=onp.set_perspective(fovy, aspect, zn, zf), view_pos=eye)
+    onp.draw(W, H, mesh, onp.VS_PHONG, ps, u, color, depth, ids)
+
+    r = fr.Renderer(W, H)
+    r.set_texture(0, texA)
+    r.set_texture(1, texB)
+    r.set_uniforms(view=fr.set_look_at(eye, at, up), proj=fr.set_perspective(fovy, aspect, zn, zf), view_pos=eye, texture_slot=0)
+    sid = r.register_shader(user_shaders.TWO_TEXTURES, 8, 8)
+    r.set_user_uniforms([wa, wb])
+    m = r.upload_mesh(mesh, fr.VS_PHONG)
+    r.clear()
+    r.draw(m, sid)
+    c, d, t = r.readback()
+    np.testing.assert_array_equal(t, ids)
+    np.testing.assert_array_equal(d.view(np.uint32), depth.view(np.uint32))
+    np.testing.assert_array_equal(c, color)
+    assert len(np.unique(c.reshape(-1, 4), axis=0)) > 50     # (a textured image, not a constant)
+    r.close()
+
+
+def test_user_vertex_shader_with_a_builtin_pixel_shader_and_saturated_coordinates(oracle):
+    """The two halves of a user shader combine with the tables: a user VS (clip position + colour) drawn with the built-in
+    PS_COLOR -- on the scene whose negative / tiny w gives saturated spi and wrapping edge functions (the brute-force sweep
+    inside the span kernel, which is all a user-shaded triangle outside +-8191 has), on 1 and 2 ranks."""
+    import f_renderer_amd as fr
+    from f_renderer_amd import scenes
+    from .conftest import owned_pixel_rows
+    W, H, n = 320, 180, 1500
+    clip = scenes.random_clip_triangles(n, W, H, seed=3, spread=1.3, w_jitter=1.5)
+    col = scenes.splitmix_u01(17, n * 9).reshape(n, 3, 3).astype(np.float32)
+    tris = np.concatenate([clip, col], axis=2)
+    f = oracle.Frame(W, H)
+    f.clear((9, 8, 7, 6), 0.0)
+    f.draw(tris, oracle.VS_CLIP_COLOR, oracle.PS_COLOR, oracle.make_uniforms())
+    for world in (1, 2):
+        acc_c = np.zeros((H, W, 4), np.uint8)
+        acc_t = np.zeros(W * H, np.uint32)
+        acc_d = np.zeros(W * H, np.float32)
+        for rank in range(world):
+            r = fr.Renderer(W, H)
+            if world > 1:
+                r.set_partition(rank, world, blocked=True)
+            sid = r.register_shader(user_shaders.VERTEX_COLOR, 7, 3)
+            r.clear((9, 8, 7, 6), 0.0)
+            r.draw(r.upload_mesh(tris, sid), fr.PS_COLOR if rank == 0 else sid)    # (both pixel shaders are the same function)
+            c, d, t = r.readback()
+            own = owned_pixel_rows(H, rank, world, True)
+            acc_c[own] = c[own]
+            acc_t.reshape(H, W)[own] = t.reshape(H, W)[own]
+            acc_d.reshape(H, W)[own] = d.reshape(H, W)[own]
+            r.close()
+        np.testing.assert_array_equal(acc_t, f.tri_id)
+        from .conftest import assert_depth_equal
+        assert_depth_equal(acc_d, f.depth)
+        np.testing.assert_array_equal(acc_c, f.color)

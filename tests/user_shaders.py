@@ -70,3 +70,19 @@ BROKEN = r"""
 __device__ void frr_user_vs(const frr::DevUniforms &u, const float *in, float pos[4], float *ctx) { pos[0] = no_such_symbol; }
 __device__ void frr_user_ps(const frr::DevUniforms &u, const float *ctx, float out[4], const float *u8lut) { }
 """
+
+# a pixel shader over TWO textures (the reference's PSUniform holds three, phong.rs:41-47): slot 0 sampled at uv, slot 1
+# at the swapped coordinates, blended with two captured weights; varyings = the built-in Phong vertex shader's (K = 8)
+TWO_TEXTURES = r"""
+__device__ void frr_user_vs(const frr::DevUniforms &u, const float *in, float pos[4], float *ctx)
+{
+    pos[0] = in[0]; pos[1] = in[1]; pos[2] = in[2]; pos[3] = 1.0f;     // (unused: the mesh keeps the built-in VS_PHONG)
+}
+__device__ void frr_user_ps(const frr::DevUniforms &u, const float *ctx, float out[4], const float *u8lut)
+{
+    float a[4], b[4];
+    frr::sample_2d_slot(u, 0, ctx[0], ctx[1], a, u8lut);
+    frr::sample_2d_slot(u, 1, ctx[1], ctx[0], b, u8lut);
+    for (int k = 0; k < 4; ++k) out[k] = a[k] * u.user[0] + b[k] * u.user[1];
+}
+"""
