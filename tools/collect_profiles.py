@@ -1,14 +1,13 @@
 #!/usr/bin/env python3
-"""Dev tool: copy what tools/refresh_profiles.sh left in gpurun_out/final3/ into the committed profiles/ (r03_*)."""
+"""Dev tool: copy what tools/refresh_profiles.sh left in gpurun_out/final4/ into the committed profiles/ (r04_*)."""
 import glob, json, os, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(R, "gpurun_out", "final3")
+F = os.path.join(R, "gpurun_out", "final4")
 P = os.path.join(R, "profiles")
-TAG = "r03"
+TAG = "r04"
 one = lambda pat: max(glob.glob(os.path.join(F, pat)), key=os.path.getmtime)   # (gpurun merges into the local directory: older refreshes may still lie there)
 shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"{TAG}_bench.json"))
 shutil.copy(os.path.join(F, "configs.json"), os.path.join(P, f"{TAG}_configs.json"))
-shutil.copy(os.path.join(F, "bench_in_flight.json"), os.path.join(P, f"{TAG}_bench_in_flight.json"))
 shutil.copy(os.path.join(F, "bench_serial.json"), os.path.join(P, f"{TAG}_bench_serial.json"))
 shutil.copy(os.path.join(F, "partition_times.json"), os.path.join(P, f"{TAG}_partition_times.json"))
 shutil.copy(os.path.join(F, "partition_times_serial.json"), os.path.join(P, f"{TAG}_partition_times_serial.json"))
@@ -29,7 +28,7 @@ for w, name in WL.items():
     import re
     m = re.search(r"'bin_entries': (\d+)", open(os.path.join(F, f"f_{w}.log")).read())   # (tools/pmc_frame.py prints the frame's statistics)
     subprocess.check_call([sys.executable, os.path.join(R, "tools", "make_pmc_traffic.py"), os.path.join(F, f"fetch_{w}"), os.path.join(F, f"write_{w}"), name, traffic,
-                           m.group(1) if m else "0"])
+                           m.group(1) if m else "0", os.path.join(F, f"sq1_{w}")])
     subprocess.check_call([sys.executable, os.path.join(R, "tools", "pmc_summary.py"), os.path.join(F, f"sq1_{w}"), os.path.join(F, f"sq2_{w}"),
                            "--json", os.path.join(P, f"{TAG}_pmc", f"{w}_sq_summary.json")], stdout=subprocess.DEVNULL)
 b = json.load(open(os.path.join(P, f"{TAG}_bench.json")))

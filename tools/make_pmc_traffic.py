@@ -13,8 +13,12 @@ half of 32 B x entries) and `hbm_bytes_per_launch` includes it -- an upper bound
 table walk of lightly loaded tiles are read once.  WRITE_SIZE is exact for full-line stores.
 Every entry carries the digest of the kernel sources it was measured on (`_source_sha`): bench.py reports the
 traffic only while the library it runs was built from the same sources.
-usage: make_pmc_traffic.py <fetch_dir> <write_dir> <workload> <out.json> [bin_entries]"""
-import csv, glob, hashlib, json, os, sys
+With a third counter directory (a pass holding SQ_INSTS_VALU / SQ_INSTS_SALU) the tile kernel's entry also carries
+`valu_issue`: the VALU / SALU instructions one launch issues and the mean issue cost of one of its VALU instructions
+(tools/valu_mix.py: static mix of the kernel's ISA x the measured per-kind costs) -- what bench.py prices the VALU-issue
+bound with.
+usage: make_pmc_traffic.py <fetch_dir> <write_dir> <workload> <out.json> [bin_entries [sq_dir]]"""
+import csv, glob, hashlib, json, os, re, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,6 +46,9 @@ def mean_counter(d, name):
 def main():
     fd, wd, workload, out = sys.argv[1:5]
     bin_entries = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    sq_dir = sys.argv[6] if len(sys.argv) > 6 else None
+    valu = mean_counter(sq_dir, "SQ_INSTS_VALU") if sq_dir else {}
+    salu = mean_counter(sq_dir, "SQ_INSTS_SALU") if sq_dir else {}
     fetch, write = mean_counter(fd, "FETCH_SIZE"), mean_counter(wd, "WRITE_SIZE")
     res = json.load(open(out)) if os.path.exists(out) else {}
     entry = {"_source_sha": source_sha()}
@@ -60,6 +67,14 @@ def main():
         entry[name] = {"kernel": short, "fetch_size_kib": round(f_kib, 1), "write_size_kib": round(w_kib, 1),
                        "fetch_correction": corr, "fetch_list_correction_bytes": lists,
                        "hbm_bytes_per_launch": round((corr * f_kib + w_kib) * 1024) + lists}
+        if name == "k_raster" and k in valu:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import valu_mix
+            m = re.match(r"k_raster_span<(\d+), (\d+), (true|false), (\d+), (\d+)>", short)
+            key = "k_raster_spanILi%sELi%sELb%dELi%sELi%sEE" % (m.group(1), m.group(2), m.group(3) == "true", m.group(4), m.group(5))
+            mix = valu_mix.mix(valu_mix.isa(), key)
+            entry[name]["valu_issue"] = {"insts_valu": round(valu[k]), "insts_salu": round(salu.get(k, 0)), "cycles_per_valu": mix["cycles_per_valu"],
+                                         "static_mix": {x: mix[x] for x in ("fast", "slow", "trans")}}
     res[workload] = entry
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(workload, json.dumps(entry.get("k_raster")))

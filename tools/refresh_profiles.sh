@@ -1,14 +1,13 @@
 #!/bin/bash
-# Dev tool, run on the GPU box (gpurun): everything profiles/r03_* is generated from, written under gpurun_out/final3/.
+# Dev tool, run on the GPU box (gpurun): everything profiles/r04_* is generated from, written under gpurun_out/final4/.
 #   gpurun -- 'bash tools/refresh_profiles.sh'   then   python tools/collect_profiles.py
 # rocprofv3: the program itself follows `--` (python3 ...), kernel trace only next to --pmc (separate passes per counter set).
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/final3; [ -z "$PART2" ] && rm -rf $O; mkdir -p $O
+O=gpurun_out/final4; [ -z "$PART2" ] && rm -rf $O; mkdir -p $O
 if [ -z "$PART2" ]; then
 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
 FRR_FRAMES_IN_FLIGHT=1 FRR_OVERLAP=0 python bench.py --cpu-baseline-seconds 0 > $O/bench_serial.json 2>> $O/bench.err || exit 1   # one frame at a time, one stream (round 2's mode)
-python bench.py --in-flight --also none --cpu-baseline-seconds 0 > $O/bench_in_flight.json 2>> $O/bench.err || exit 1
 # kernel trace + stats of the default command (two frames in flight); the counter passes, workgroup shapes and tile timelines
 # look at kernels one frame at a time on one stream (FRR_FRAMES_IN_FLIGHT=1 FRR_OVERLAP=0): comparable with round 2
 for w in headline cfg4 cfg5; do
