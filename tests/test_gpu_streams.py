@@ -1,6 +1,8 @@
 """Two frames in flight: consecutive frames run on two streams with their own target sets, workspace sets and device-table
 lanes (own targets: default; caller-bound targets: option bound_targets_in_flight + frr_frame_fence).  Alternating two
 DIFFERENT scenes from frame to frame, without a host synchronisation in between, every frame must come out as the oracle's."""
+import os
+
 import numpy as np
 import pytest
 
@@ -42,12 +44,15 @@ def test_bound_targets_in_flight_with_fences(oracle, monkeypatch, tiny_lists):
 
     for i in range(9):
         c_, d_, t_ = sets[i % 3]
-        r.frame_wait(st.cuda_stream)      # the copies that still read this set (three frames back) come first
+        if not os.environ.get("FRR_TEST_SKIP_FRAME_WAIT"):   # (a manual negative control: the test must fail without the call)
+            r.frame_wait(st.cuda_stream)  # the copies that still read this set (three frames back) come first
         r.bind_targets(c_.data_ptr(), d_.data_ptr(), t_.data_ptr())
         r.clear((7, 7, 7, 7), 0.0)
         r.draw(meshes[i % 2], fr.PS_COLOR)
         r.frame_fence(st.cuda_stream)
         with torch.cuda.stream(st):
+            if i % 3 == 1:
+                torch.cuda._sleep(30_000_000)     # a slow reader: the set's next frame (three on) must wait for these copies
             taken.append((i, c_.clone(), d_.clone(), t_.clone()))
     torch.cuda.synchronize()
     assert len(taken) == 9
