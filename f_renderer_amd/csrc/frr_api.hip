@@ -44,6 +44,7 @@ struct Mesh {
     bool owned = false, used = false;
     uint64_t ntris = 0;
     int vs = 0;
+    uint64_t gen = 0;   // which registration of the ctx this is (DrawSig: a later mesh may live at a freed one's address)
 };
 struct Texture {
     uint8_t *dev = nullptr;
@@ -151,7 +152,7 @@ struct FrameState {
     bool scan_pending = false;     // its block sums are not scanned yet (geom_scan: by the binning launch, or k_geom_scan)
     int geom_vs = -1;              // VS of the latest frr_geometry
     uint64_t geom_ntris = 0;
-    const float *geom_mesh = nullptr; uint64_t geom_duni_hash = 0;   // ... its mesh and (a digest of) its uniforms: DrawSig
+    const float *geom_mesh = nullptr; uint64_t geom_mesh_gen = 0, geom_duni_hash = 0;   // ... its mesh and (a digest of) its uniforms: DrawSig
 };
 
 struct Cmd {
@@ -170,7 +171,7 @@ struct Cmd {
 
 // What decides how much of the work lists (fan space, (triangle, tile) records) a raster pass and its geometry pass need.
 struct DrawSig {
-    const float *mesh; uint64_t ntris; uint64_t duni_hash; uint32_t join_epoch;
+    const float *mesh; uint64_t mesh_gen; uint64_t ntris; uint64_t duni_hash; uint32_t join_epoch;
     int32_t vs, x0, x1, y0, y1, rank, world, blocked, filter, fy0, fy1, gset, bset;
 };
 inline bool same_sig(const DrawSig &a, const DrawSig &b) { return memcmp(&a, &b, sizeof a) == 0; }
@@ -230,6 +231,7 @@ struct frr_ctx {
     // VERIFIED before frr_raster returns: the host waits for the pass's binning launch (not for its tile kernel), looks at
     // host_bad, and repairs (finish(): grow + replay) if the pass or its geometry overflowed.  A proven pass is not waited for.
     std::vector<DrawSig> proven;
+    uint64_t mesh_gen = 0;          // meshes registered so far (Mesh::gen)
     hipEvent_t ev_verify = nullptr;
     bool verify_pending = false;
     DrawSig verify_sig;
@@ -740,7 +742,7 @@ int exec_geometry(frr_ctx *c, Cmd &cmd)
     f.geom_nblocks = nblocks;
     f.geom_seq = cmd.seq;
     f.geom_vs = m.vs; f.geom_ntris = nt;
-    f.geom_mesh = m.dev;   // (the uniforms' float fields: the struct has padding in front of its texture pointer)
+    f.geom_mesh = m.dev; f.geom_mesh_gen = m.gen;   // (the uniforms' float fields: the struct has padding in front of its texture pointer)
     f.geom_duni_hash = fnv1a(&cmd.duni, offsetof(DevUniforms, flat_color) + sizeof cmd.duni.flat_color) ^ (fnv1a(cmd.duni.user, sizeof cmd.duni.user) * 31u);
     f.tris_in += nt; f.draws += 1;
     if (nt == 0) {
@@ -866,7 +868,7 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
         // does this pass's need of the work lists fit for sure?  (exec_cmd waits for the event if not: frr_ctx::proven)
         DrawSig sig;
         memset(&sig, 0, sizeof sig);
-        sig.mesh = f.geom_mesh; sig.ntris = f.geom_ntris; sig.duni_hash = f.geom_duni_hash; sig.join_epoch = c->join_epoch;
+        sig.mesh = f.geom_mesh; sig.mesh_gen = f.geom_mesh_gen; sig.ntris = f.geom_ntris; sig.duni_hash = f.geom_duni_hash; sig.join_epoch = c->join_epoch;
         sig.vs = f.geom_vs; sig.x0 = x0; sig.x1 = x1; sig.y0 = y0; sig.y1 = y1; sig.rank = f.rank; sig.world = f.world;
         sig.blocked = f.part_blocked ? 1 : 0; sig.filter = f.geom_filter.active ? 1 : 0; sig.fy0 = f.geom_filter.y0; sig.fy1 = f.geom_filter.y1;
         sig.gset = f.gset; sig.bset = bi;
@@ -1302,7 +1304,7 @@ int frr_target_ptrs(frr_ctx *c, void **color, void **depth, void **tri_id)
 
 static int mesh_register(frr_ctx *c, const float *dev, bool owned, uint64_t ntris, int vs, int *mesh_out)
 {
-    Mesh m; m.dev = dev; m.owned = owned; m.used = true; m.ntris = ntris; m.vs = vs;
+    Mesh m; m.dev = dev; m.owned = owned; m.used = true; m.ntris = ntris; m.vs = vs; m.gen = ++c->mesh_gen;
     for (size_t i = 0; i < c->meshes.size(); ++i)
         if (!c->meshes[i].used) { c->meshes[i] = m; *mesh_out = (int)i; return FRR_OK; }
     c->meshes.push_back(m);

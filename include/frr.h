@@ -257,7 +257,9 @@ int frr_draw(frr_ctx *ctx, int mesh, int ps_id, int32_t x0, int32_t x1, int32_t 
  * The frames it fences are whole: like the reference's draw (renderer.rs:269-384 has no failure path) a draw of this
  * library cannot fail -- a raster pass whose need of the internal work lists is not known to fit is checked on the host,
  * and repaired, before frr_raster / frr_draw returns (the call then waits for the pass's binning launch, not for its tile
- * kernel; a pass that repeats a mesh, uniforms, window and partition already seen to fit is not waited for). */
+ * kernel; a pass that repeats a mesh, uniforms, window and partition already seen to fit is not waited for).
+ * `stream` has to stay alive until the second frr_clear from now when it fenced the ctx's OWN targets (that frr_clear
+ * records an event on it: frr_target_ptrs). */
 int frr_frame_fence(frr_ctx *ctx, void *stream);
 /* The reverse edge: the next kernel that WRITES the frame targets (the pending frr_clear, the next tile kernel) waits for
  * what `stream` (NULL = the ctx's stream) holds now -- e.g. an exchange that still reads a caller-bound target set which is
