@@ -57,7 +57,7 @@ constexpr int kSpanShapes[6][2] = {{16, 4}, {8, 6}, {6, 6}, {4, 8}, {4, 6}, {LIG
 struct UserShader {
     int nf = 0, K = 0;
     std::vector<char> code;
-    std::string geom, clip, span[2][6];   // lowered kernel names ([count fragments][shape])
+    std::string geom, clip, sweep, span[2][6];   // lowered kernel names ([count fragments][shape]; sweep: the brute-force tile kernel)
 };
 std::mutex g_shader_mu;
 std::vector<UserShader *> g_shaders;      // id = FRR_SHADER_USER_BASE + index; never shrinks
@@ -92,7 +92,7 @@ void release_stream(int device, hipStream_t st)
 
 struct UserModule {
     hipModule_t mod = nullptr;
-    hipFunction_t geom = nullptr, clip = nullptr, span[2][6] = {};
+    hipFunction_t geom = nullptr, clip = nullptr, sweep = nullptr, span[2][6] = {};
 };
 
 // Workspace of one geometry pass / one raster pass.  There are two of each, used alternately (parity of the pass), so
@@ -513,6 +513,7 @@ int user_module(frr_ctx *c, int id, const UserModule **out)
     HIP_TRY(c, hipModuleLoadData(&m.mod, us->code.data()));
     HIP_TRY(c, hipModuleGetFunction(&m.geom, m.mod, us->geom.c_str()));
     HIP_TRY(c, hipModuleGetFunction(&m.clip, m.mod, us->clip.c_str()));
+    HIP_TRY(c, hipModuleGetFunction(&m.sweep, m.mod, us->sweep.c_str()));
     for (int cnt = 0; cnt < 2; ++cnt)
         for (int sh = 0; sh < 6; ++sh) HIP_TRY(c, hipModuleGetFunction(&m.span[cnt][sh], m.mod, us->span[cnt][sh].c_str()));
     *out = &(c->user_modules[id] = m);
@@ -893,7 +894,8 @@ int exec_raster(frr_ctx *c, Cmd &cmd)
         const int win_safe = a.x0 >= -SPAN_SAFE && a.y0 >= -SPAN_SAFE && a.x1 <= SPAN_SAFE && a.y1 <= SPAN_SAFE;
         RasterArgs ra = a; DevUniforms d = cmd.duni; int ws = win_safe;
         void *args[] = {&ra, &d, &ws};
-        (void)hipModuleLaunchKernel(um->span[cmd.count_frags ? 1 : 0][shi], grid, 1, 1, (unsigned)kSpanShapes[shi][0] * 64u, 1, 1, 0, ts, args, nullptr);
+        if (c->raster_sweep) (void)hipModuleLaunchKernel(um->sweep, grid, 1, 1, 256, 1, 1, 0, ts, args, nullptr);   // k_raster(RasterArgs, DevUniforms)
+        else (void)hipModuleLaunchKernel(um->span[cmd.count_frags ? 1 : 0][shi], grid, 1, 1, (unsigned)kSpanShapes[shi][0] * 64u, 1, 1, 0, ts, args, nullptr);
     } else if (grid) {
         switch (ps_id) {
         case FRR_PS_DEPTH: launch_raster<0, FRR_PS_DEPTH>(c, a, grid, sh, cmd.duni, cmd.count_frags); break;
@@ -1397,6 +1399,8 @@ int frr_shader_register(frr_ctx *c, const char *hip_source, int vs_input_floats,
     us->nf = vs_input_floats; us->K = num_varyings;
     const std::string U = std::to_string(FRR_SHADER_USER_BASE), Ks = std::to_string(num_varyings);
     std::vector<std::string> exprs = {"frr::k_geom_single<" + U + ">", "frr::k_geom_clip<" + U + ">"};
+    const std::string sweep_expr = "frr::k_raster<" + Ks + ", " + U + ">";   // the brute-force tile kernel (option raster_sweep)
+    (void)hiprtcAddNameExpression(prog, sweep_expr.c_str());
     for (int cnt = 0; cnt < 2; ++cnt)
         for (int sh = 0; sh < 6; ++sh)
             exprs.push_back("frr::k_raster_span<" + Ks + ", " + U + ", " + (cnt ? "true" : "false") + ", " + std::to_string(kSpanShapes[sh][0]) + ", " + std::to_string(kSpanShapes[sh][1]) + ">");
@@ -1414,7 +1418,7 @@ int frr_shader_register(frr_ctx *c, const char *hip_source, int vs_input_floats,
     }
     bool ok = true;
     auto lowered = [&](const std::string &e) { const char *n = nullptr; ok = ok && hiprtcGetLoweredName(prog, e.c_str(), &n) == HIPRTC_SUCCESS && n; return std::string(n ? n : ""); };
-    us->geom = lowered(exprs[0]); us->clip = lowered(exprs[1]);
+    us->geom = lowered(exprs[0]); us->clip = lowered(exprs[1]); us->sweep = lowered(sweep_expr);
     for (int cnt = 0; cnt < 2; ++cnt)
         for (int sh = 0; sh < 6; ++sh) us->span[cnt][sh] = lowered(exprs[2 + (size_t)cnt * 6 + sh]);
     size_t cs = 0;
@@ -1518,7 +1522,6 @@ static int raster_check(frr_ctx *c, int ps_id, int32_t x0, int32_t x1, int32_t y
         const UserShader *us = user_shader(ps_id);
         if (!us) return fail(c, FRR_ERR_INVALID, "unknown shader id");
         if (us->K != K) return fail(c, FRR_ERR_INVALID, "the user pixel shader's varyings do not match the vertex shader's");
-        if (c->raster_sweep) return fail(c, FRR_ERR_UNSUPPORTED, "the brute-force tile kernel (option raster_sweep) is not generated for user shaders");
     } else if ((ps_id == FRR_PS_COLOR && K != 3) || ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && K != 8) || ps_id < 0 || ps_id > FRR_PS_BLINN)
         return fail(c, FRR_ERR_INVALID, "pixel shader does not match the vertex shader's varyings");
     if ((ps_id == FRR_PS_PHONG || ps_id == FRR_PS_BLINN) && !c->duni.tex) return fail(c, FRR_ERR_INVALID, "no texture bound to uniforms.texture_slot");

@@ -94,8 +94,7 @@ typedef enum frr_ps {
  * tables: a mesh uploaded with a user id may be drawn with a built-in ps_id, and a mesh with a built-in (or another
  * user) vs_id with a user ps_id -- provided the pixel shader's varyings are the vertex shader's (frr_vs_num_varyings;
  * FRR_ERR_INVALID otherwise).  ctx may be NULL (compile only: the registry is per process; a ctx loads the code object
- * on first use).  A source that does not compile: FRR_ERR_UNSUPPORTED, with the compiler's log in frr_last_error(ctx).
- * The brute-force tile kernel (option raster_sweep) is not generated for user shaders. */
+ * on first use).  A source that does not compile: FRR_ERR_UNSUPPORTED, with the compiler's log in frr_last_error(ctx). */
 int frr_shader_register(frr_ctx *ctx, const char *hip_source, int vs_input_floats, int num_varyings, int *shader_id);
 /* u.user[0..n) for the draws issued from now on (n <= FRR_MAX_USER_UNIFORMS; travels with each draw like frr_uniforms) */
 int frr_set_user_uniforms(frr_ctx *ctx, const float *values, int n);

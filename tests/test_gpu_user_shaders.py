@@ -57,7 +57,7 @@ def test_phong_as_user_shader_equals_the_builtin_and_the_oracle(oracle, nw):
     np.testing.assert_array_equal(d.view(np.uint32), f.depth.view(np.uint32))
 
 
-@pytest.mark.parametrize("world", [1, 3])
+@pytest.mark.parametrize("world", [1, 3, -1])
 def test_vertex_colour_user_shader_on_clipped_triangles(oracle, world):
     """K = 3 varyings through the clipper (intersection vertices interpolate the user's varyings, renderer.rs:88-91) and on a
     partitioned ctx; against the oracle's VS_CLIP_COLOR / PS_COLOR frame."""
@@ -75,8 +75,12 @@ def test_vertex_colour_user_shader_on_clipped_triangles(oracle, world):
         pytest.skip("NaN rhw")
     acc_c = np.zeros((H, W, 4), np.uint8)
     acc_t = np.zeros(W * H, np.uint32)
+    sweep = world < 0                     # world -1: one rank, the brute-force tile kernel of the user's module (option raster_sweep)
+    world = abs(world)
     for rank in range(world):
         r = fr.Renderer(W, H)
+        if sweep:
+            r.set_option("raster_sweep", 1)
         if world > 1:
             r.set_partition(rank, world, blocked=True)
         sid = r.register_shader(user_shaders.VERTEX_COLOR, 7, 3)
@@ -133,10 +137,8 @@ def test_user_shader_errors():
     with pytest.raises(fr.FrrError) as e:
         r.draw(m, sid3)                             # ... and so does this user pixel shader
     assert e.value.code == fr.FRR_ERR_INVALID
-    r.set_option("raster_sweep", 1)
-    with pytest.raises(fr.FrrError) as e:
-        r.draw(m, sid)
-    assert e.value.code == fr.FRR_ERR_UNSUPPORTED
+    r.set_option("raster_sweep", 1)                # (the brute-force tile kernel is generated for user shaders too)
+    r.draw(m, sid)
     r.set_option("raster_sweep", 0)
     r.draw(m, sid)
     r.sync()
