@@ -31,7 +31,7 @@ extern "C" {
 #define FRR_ABI_VERSION 4
 #define FRR_MAX_VARYINGS 16
 #define FRR_MAX_TEXTURES 4
-#define FRR_MAX_USER_UNIFORMS 32 /* f32 a user shader receives (frr_set_user_uniforms) */
+#define FRR_MAX_USER_UNIFORMS 64 /* f32 a user shader receives (frr_set_user_uniforms) */
 #define FRR_SHADER_USER_BASE 64  /* ids of user shaders (frr_shader_register) start here */
 #define FRR_MAX_OUT_TRIS 19 /* 3 + 18 clip vertices -> 19 fan triangles (renderer.rs:150-171,245-264) */
 
