@@ -6,7 +6,8 @@ F = os.path.join(R, "gpurun_out", "final4")
 P = os.path.join(R, "profiles")
 TAG = "r04"
 one = lambda pat: max(glob.glob(os.path.join(F, pat)), key=os.path.getmtime)   # (gpurun merges into the local directory: older refreshes may still lie there)
-shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"{TAG}_bench.json"))
+if not os.environ.get("PMC_ONLY"):   # (tools/refresh_pmc.sh refreshes the counter passes alone: the bench lines stay)
+    shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"{TAG}_bench.json"))
 shutil.copy(os.path.join(F, "configs.json"), os.path.join(P, f"{TAG}_configs.json"))
 shutil.copy(os.path.join(F, "bench_serial.json"), os.path.join(P, f"{TAG}_bench_serial.json"))
 shutil.copy(os.path.join(F, "partition_times.json"), os.path.join(P, f"{TAG}_partition_times.json"))
