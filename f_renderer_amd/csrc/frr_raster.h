@@ -185,7 +185,9 @@ __device__ __forceinline__ void tile_resolve(const RasterArgs &a, const DevUnifo
         Frag f = frag_eval(u2f(q1.z), u2f(q1.w), u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w), r0, r1, r2, cx, cy);
         const size_t di = (size_t)(c.ly0 + y) * a.dstride + (c.lx0 + x);
         a.depth[di] = f.rhw;                                                    // :366
-        a.tri_id[di] = id_emission(a, tri_base, id);
+        // (the record is here anyway, and its flags carry the triangle's emission offset within its geometry block: one table
+        // lookup instead of id_emission's two dependent ones)
+        a.tri_id[di] = tri_base + a.block_prefix[((id - 1u) >> FAN_BITS) / GEOM_BLOCK] + ((q3.w >> REC_EOFF_SHIFT) & REC_EOFF_MASK);
         if constexpr (PS != FRR_PS_DEPTH) {
             const float w = recip_exact(f.rhw != 0.0f ? f.rhw : 1.0f);          // :368 (== 1.0f / x, bit for bit)
             const float c0 = r0 * f.a * w, c1 = r1 * f.b * w, c2 = r2 * f.c * w; // :370-372
