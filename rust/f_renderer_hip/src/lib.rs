@@ -257,6 +257,26 @@ impl Renderer {
         self.check(unsafe { ffi::frr_target_ptrs(self.ctx, &mut c, &mut d, &mut t) })?;
         Ok((c, d, t))
     }
+    /// `stream` (a hipStream_t; null = the renderer's) waits for every frame issued so far: what is enqueued on it next
+    /// sees their targets (no host wait)
+    pub fn frame_fence(&mut self, stream: *mut c_void) -> Result<(), Error> {
+        self.check(unsafe { ffi::frr_frame_fence(self.ctx, stream) })
+    }
+    /// the next write of the frame targets waits for what `stream` holds now (a reader of a target set that is bound again)
+    pub fn frame_wait(&mut self, stream: *mut c_void) -> Result<(), Error> {
+        self.check(unsafe { ffi::frr_frame_wait(self.ctx, stream) })
+    }
+}
+
+/// The final-image exchange of one row-major plane for `rank` of `world` (blocked layout), as the list of operations one
+/// RCCL group posts per frame (`examples/gather_rccl.cpp`); a pure function, no device
+pub fn exchange_plan(height: i32, row_elems: u32, rank: i32, world: i32, root: i32) -> Vec<ffi::frr_xfer> {
+    let n = unsafe { ffi::frr_exchange_plan(0, height, row_elems, rank, world, 1, root, std::ptr::null_mut(), 0) };
+    let mut ops = vec![ffi::frr_xfer::default(); n.max(0) as usize];
+    if n > 0 {
+        unsafe { ffi::frr_exchange_plan(0, height, row_elems, rank, world, 1, root, ops.as_mut_ptr(), n) };
+    }
+    ops
 }
 
 impl Drop for Renderer {
