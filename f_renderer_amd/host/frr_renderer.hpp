@@ -321,6 +321,10 @@ public:
         check(frr_draw(ctx_, m.id, pixel_shader, 0, (int32_t)width_, 0, (int32_t)height_));
     }
     void sync() { check(frr_sync(ctx_)); }
+    // stream-side ordering against a caller's hipStream_t (nullptr: the renderer's own), no host wait: frame_fence -- the stream
+    // waits for every frame issued so far; frame_wait -- the next write of the frame targets waits for what the stream holds now
+    void frame_fence(void *stream = nullptr) { check(frr_frame_fence(ctx_, stream)); }
+    void frame_wait(void *stream = nullptr) { check(frr_frame_wait(ctx_, stream)); }
 
     // image_slice.copy_from_slice(frame_buffer.get_data())   (phong.rs:386)
     void read_frame_buffer(FrameBuffer &fb)
